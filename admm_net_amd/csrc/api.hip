@@ -1,0 +1,458 @@
+// api.hip -- the extern "C" boundary declared in include/admmnet.h: host-side
+// weight packing, workspace carving and the per-layer launch sequence.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace admmnet {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+static int check_cfg(const admmnet_cfg *cfg) {
+    if (!cfg) {
+        set_error("cfg is NULL");
+        return ADMMNET_E_ARG;
+    }
+    const int64_t D = (int64_t)cfg->M * cfg->N;
+    if (cfg->M < 1 || cfg->N < 1 || D < 1 || D > kMaxD) {
+        set_error("unsupported geometry M=%d N=%d (need 1 <= M*N <= %d)", cfg->M, cfg->N, kMaxD);
+        return ADMMNET_E_ARG;
+    }
+    if (cfg->K < 1 || cfg->K > 1024) {
+        set_error("unsupported num_layers K=%d", cfg->K);
+        return ADMMNET_E_ARG;
+    }
+    if (cfg->has_head && (cfg->L < 1 || cfg->L > 16)) {
+        set_error("unsupported L=%d", cfg->L);
+        return ADMMNET_E_ARG;
+    }
+    return ADMMNET_OK;
+}
+
+int64_t pick_chunk(const admmnet_cfg *cfg, int64_t B) {
+    int64_t c = cfg->chunk > 0 ? cfg->chunk : 8192;
+    if (c > B) c = B;
+    if (c < 1) c = 1;
+    return c;
+}
+
+// carve helper
+struct Carver {
+    char *base;
+    int64_t off = 0;
+    template <class T>
+    T *take(int64_t count) {
+        T *p = reinterpret_cast<T *>(base + off);
+        off = align_up(off + (int64_t)sizeof(T) * count, 256);
+        return p;
+    }
+};
+
+static void carve_chunk(Carver &c, int D, int64_t chunk, Ws *ws) {
+    const int64_t n = D + 1;
+    ws->chunk = chunk;
+    ws->cap = (int64_t)kLogCapMul * n * n;
+    ws->Mbuf = c.take<float2>(chunk * ((int64_t)D * D + D + 1));
+    ws->QV = c.take<float>(chunk * n * 2 * D);
+    const int64_t groups = (chunk + 63) / 64;
+    ws->dT = c.take<float>(groups * n * 64);
+    ws->eT = c.take<float>(groups * n * 64);
+    ws->w = c.take<float>(chunk * n);
+    ws->w0 = c.take<float>(chunk * n);
+    ws->log = c.take<LogRec>(chunk * (ws->cap + 16));
+    ws->logn = c.take<int>(chunk * 2);
+}
+
+int64_t eig_chunk_bytes(int D, int64_t chunk) {
+    Carver c{nullptr};
+    Ws ws;
+    carve_chunk(c, D, chunk, &ws);
+    return c.off;
+}
+
+int carve_workspace(const admmnet_cfg *cfg, int64_t B, void *base, int64_t bytes, Ws *ws, bool state) {
+    const int D = cfg->M * cfg->N;
+    const int64_t n = D + 1;
+    Carver c{reinterpret_cast<char *>(base)};
+    memset(ws, 0, sizeof(*ws));
+    if (state) {
+        ws->G = c.take<float2>(B * n * n);
+        ws->Z = c.take<float2>(B * n * n);
+        for (int i = 0; i < 2; ++i) ws->phi[i] = c.take<float2>(B * D);
+        for (int i = 0; i < 2; ++i) ws->h[i] = c.take<float>(B * D);
+        ws->alpha = c.take<float>(B);
+        ws->rn = c.take<float>(B);
+        ws->sum = c.take<double>(2);
+        ws->mean = c.take<float>(4);
+        ws->headkv = c.take<float>((int64_t)2 * D * 128);
+    }
+    carve_chunk(c, D, pick_chunk(cfg, B), ws);
+    ws->total_bytes = c.off;
+    if (base && bytes < c.off) {
+        set_error("workspace too small: %lld < %lld bytes", (long long)bytes, (long long)c.off);
+        return ADMMNET_E_WORKSPACE;
+    }
+    return ADMMNET_OK;
+}
+
+static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st) {
+    int rc;
+    if ((rc = launch_tridiag(D, nb, ws, st))) return rc;
+    if ((rc = launch_tql(D + 1, nb, ws, status, st))) return rc;
+    if ((rc = launch_rotapply(D, nb, ws, st))) return rc;
+    return ADMMNET_OK;
+}
+
+}  // namespace admmnet
+
+using namespace admmnet;
+
+extern "C" {
+
+int admmnet_abi_version(void) { return ADMMNET_ABI_VERSION; }
+const char *admmnet_last_error(void) { return g_err; }
+
+int64_t admmnet_raw_weight_count(const admmnet_cfg *cfg) {
+    if (check_cfg(cfg)) return -1;
+    const int64_t D = (int64_t)cfg->M * cfg->N;
+    const int64_t per_layer = 1 + 2 + 64 * D + 64 + D * 64 + D + 3 + 49 + 2 + 161;
+    int64_t total = per_layer * cfg->K;
+    if (cfg->has_head) {
+        const int64_t L = cfg->L;
+        total += 2 * D + 128 * 2 * D + 128 + 128 * 128 + 128 + 256 + 128 + 384 * 128 + 384 + 128 * 128 + 128 +
+                 64 * 128 + 64 + 32 * 64 + 32 + 16 * 32 + 16 + L * 2 * (32 * 16 + 32 + 32 + 1) +
+                 16 * 16 + 16 + 16 + 1;
+    }
+    return total;
+}
+
+int64_t admmnet_layer_weight_offset(const admmnet_cfg *cfg, int32_t k) {
+    if (check_cfg(cfg)) return -1;
+    const LayerLayout L{cfg->M * cfg->N};
+    return (int64_t)k * L.size();
+}
+
+int64_t admmnet_packed_weight_count(const admmnet_cfg *cfg) {
+    if (check_cfg(cfg)) return -1;
+    const int D = cfg->M * cfg->N;
+    const LayerLayout L{D};
+    int64_t total = (int64_t)cfg->K * L.size();
+    if (cfg->has_head) total += HeadLayout{D, cfg->L}.size();
+    return total;
+}
+
+// transpose src[rows][cols] -> dst[cols][rows]
+static void tr(const float *src, int rows, int cols, float *dst) {
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) dst[(size_t)c * rows + r] = src[(size_t)r * cols + c];
+}
+
+int admmnet_pack_weights(const admmnet_cfg *cfg, const float *raw, float *out) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!raw || !out) {
+        set_error("pack_weights: NULL buffer");
+        return ADMMNET_E_ARG;
+    }
+    const int D = cfg->M * cfg->N;
+    const LayerLayout L{D};
+    memset(out, 0, sizeof(float) * (size_t)admmnet_packed_weight_count(cfg));
+    const float *p = raw;
+    for (int k = 0; k < cfg->K; ++k) {
+        float *o = out + (size_t)k * L.size();
+        const float rho_phi = *p++;
+        const float rho_h = *p++, pw = *p++;
+        const float *w1 = p; p += 64 * D;
+        const float *b1 = p; p += 64;
+        const float *w2 = p; p += D * 64;
+        const float *b2 = p; p += D;
+        const float lam_g = *p++, rho_g = *p++, thr = *p++;
+        const float *vn = p; p += 49;
+        const float rho_z = *p++, lam_z = *p++;
+        const float *rs = p; p += 161;
+        // fp32 arithmetic, mirroring the reference tensors (admm_net.py:97,148,188,269-271,287-288,321,406,424-426,457)
+        o[S_RHO_PHI] = softplus_f(rho_phi);
+        o[S_RHO_H_EPS] = softplus_f(rho_h) + kEpsRef;
+        o[S_SIG_PW] = sigmoid_f(pw);
+        {
+            const float lv = softplus_f(lam_g);
+            o[S_CORNER_G] = 1.0f / (lv * lv + kEpsRef);
+        }
+        o[S_INV_RHO_G] = 1.0f / (softplus_f(rho_g) + kEpsRef);
+        o[S_THR] = sigmoid_f(thr);
+        o[S_RHO_Z] = softplus_f(rho_z);
+        {
+            const float lv = softplus_f(lam_z);
+            o[S_CORNER_Z] = 1.0f / (lv * lv + kEpsRef);
+        }
+        o[S_KNORM] = (float)((double)k / 10.0);
+        o[S_A_COEF] = 2.0f * sqrtf((float)D);
+        tr(w1, 64, D, o + L.off_w1t());           // [64][D] -> [D][64]
+        memcpy(o + L.off_b1(), b1, sizeof(float) * 64);
+        tr(w2, D, 64, o + L.off_w2t());           // [D][64] -> [64][D]
+        memcpy(o + L.off_b2(), b2, sizeof(float) * D);
+        memcpy(o + L.off_vn(), vn, sizeof(float) * 49);
+        memcpy(o + L.off_rs(), rs, sizeof(float) * 161);
+    }
+    if (cfg->has_head) {
+        const HeadLayout H{D, cfg->L};
+        float *o = out + (size_t)cfg->K * L.size();
+        memcpy(o + H.off_pos(), p, sizeof(float) * 2 * D); p += 2 * D;
+        tr(p, 128, 2 * D, o + H.off_fe0w()); p += 128 * 2 * D;
+        memcpy(o + H.off_fe0b(), p, sizeof(float) * 128); p += 128;
+        tr(p, 128, 128, o + H.off_fe2w()); p += 128 * 128;
+        memcpy(o + H.off_fe2b(), p, sizeof(float) * 128); p += 128;
+        memcpy(o + H.off_ppw(), p, sizeof(float) * 256); p += 256;
+        memcpy(o + H.off_ppb(), p, sizeof(float) * 128); p += 128;
+        tr(p, 384, 128, o + H.off_inw()); p += 384 * 128;
+        memcpy(o + H.off_inb(), p, sizeof(float) * 384); p += 384;
+        tr(p, 128, 128, o + H.off_outw()); p += 128 * 128;
+        memcpy(o + H.off_outb(), p, sizeof(float) * 128); p += 128;
+        tr(p, 64, 128, o + H.off_pe0w()); p += 64 * 128;
+        memcpy(o + H.off_pe0b(), p, sizeof(float) * 64); p += 64;
+        tr(p, 32, 64, o + H.off_pe2w()); p += 32 * 64;
+        memcpy(o + H.off_pe2b(), p, sizeof(float) * 32); p += 32;
+        tr(p, 16, 32, o + H.off_pe4w()); p += 16 * 32;
+        memcpy(o + H.off_pe4b(), p, sizeof(float) * 16); p += 16;
+        for (int t = 0; t < cfg->L; ++t) {
+            float *r = o + H.off_reg(t);
+            for (int q = 0; q < 2; ++q) {      // tau then f
+                tr(p, 32, 16, r); p += 32 * 16;                     // [32][16] -> [16][32]
+                memcpy(r + 512, p, sizeof(float) * 32); p += 32;    // b1
+                memcpy(r + 544, p, sizeof(float) * 32); p += 32;    // w2
+                r[576] = *p++;                                      // b2
+                r += 577;
+            }
+        }
+        float *c = o + H.off_conf();
+        tr(p, 16, 16, c); p += 256;
+        memcpy(c + 256, p, sizeof(float) * 16); p += 16;
+        memcpy(c + 272, p, sizeof(float) * 16); p += 16;
+        c[288] = *p++;
+    }
+    if (p - raw != admmnet_raw_weight_count(cfg)) {
+        set_error("pack_weights: internal count mismatch %lld vs %lld", (long long)(p - raw),
+                  (long long)admmnet_raw_weight_count(cfg));
+        return ADMMNET_E_ARG;
+    }
+    return ADMMNET_OK;
+}
+
+int64_t admmnet_workspace_bytes(const admmnet_cfg *cfg, int64_t B) {
+    if (check_cfg(cfg) || B < 1) return -1;
+    Ws ws;
+    carve_workspace(cfg, B, nullptr, 0, &ws, true);
+    return ws.total_bytes;
+}
+
+int admmnet_begin(const admmnet_cfg *cfg, int64_t B, void *workspace, int64_t workspace_bytes,
+                  int32_t *status, void *stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (B < 1 || !workspace) {
+        set_error("begin: bad B or workspace");
+        return ADMMNET_E_ARG;
+    }
+    Ws ws;
+    if ((rc = carve_workspace(cfg, B, workspace, workspace_bytes, &ws, true))) return rc;
+    if (status) ADMM_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), (hipStream_t)stream));
+    return ADMMNET_OK;
+}
+
+int admmnet_layer_front(const admmnet_cfg *cfg, const float *W, int32_t k, const void *y, const void *b,
+                        const float *sigma, int64_t B, void *workspace, double *sum_out, int32_t *status,
+                        void *stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (k < 0 || k >= cfg->K || B < 1 || !W || !y || !b || !sigma || !workspace) {
+        set_error("layer_front: bad argument");
+        return ADMMNET_E_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    Ws ws;
+    carve_workspace(cfg, B, workspace, INT64_MAX, &ws, true);
+    const int D = cfg->M * cfg->N;
+    const int64_t n = D + 1;
+    const LayerLayout L{D};
+    const float2 *yy = (const float2 *)y, *bb = (const float2 *)b;
+    if (k == cfg->K - 1) return launch_prep(cfg, W, k, yy, bb, sigma, 0, B, ws, true, st);
+    const float *lw = W + (int64_t)k * L.size();
+    const int cur = k & 1;
+    for (int64_t b0 = 0; b0 < B; b0 += ws.chunk) {
+        const int64_t nb = (B - b0 < ws.chunk) ? (B - b0) : ws.chunk;
+        if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, ws, false, st))) return rc;
+        if ((rc = eig_chunk(D, nb, ws, status, st))) return rc;
+        if ((rc = launch_rebuild(D, nb, lw, ws.phi[cur] + b0 * D, ws.h[cur] + b0 * D, ws.G + b0 * n * n,
+                                 ws.rn + b0, nullptr, ws, st)))
+            return rc;
+    }
+    return launch_rn_sum(B, ws.rn, sum_out ? sum_out : ws.sum, st);
+}
+
+int admmnet_layer_back(const admmnet_cfg *cfg, const float *W, int32_t k, int64_t B, void *workspace,
+                       const float *mean_dev, void *stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (k < 0 || k >= cfg->K - 1 || !mean_dev) {
+        set_error("layer_back: bad argument (k=%d)", k);
+        return ADMMNET_E_ARG;
+    }
+    Ws ws;
+    carve_workspace(cfg, B, workspace, INT64_MAX, &ws, true);
+    const int D = cfg->M * cfg->N;
+    const LayerLayout L{D};
+    return launch_zstep(W + (int64_t)k * L.size(), D, B, ws.rn, mean_dev, ws.alpha, (hipStream_t)stream);
+}
+
+int admmnet_finish(const admmnet_cfg *cfg, const float *W, int64_t B, void *workspace, void *phi_out,
+                   float *head_out, void *stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    Ws ws;
+    carve_workspace(cfg, B, workspace, INT64_MAX, &ws, true);
+    const int D = cfg->M * cfg->N;
+    const float2 *phi = ws.phi[(cfg->K - 1) & 1];
+    if (phi_out)
+        ADMM_HIP(hipMemcpyAsync(phi_out, phi, sizeof(float2) * B * D, hipMemcpyDeviceToDevice, st));
+    if (head_out) {
+        if (!cfg->has_head) {
+            set_error("finish: head_out given but cfg.has_head == 0");
+            return ADMMNET_E_ARG;
+        }
+        const LayerLayout L{D};
+        return launch_head(cfg, W + (int64_t)cfg->K * L.size(), B, phi, ws.headkv, head_out, st);
+    }
+    return ADMMNET_OK;
+}
+
+int admmnet_forward_f32(const admmnet_cfg *cfg, const float *W, const void *y, const void *b,
+                        const float *sigma, int64_t B, void *phi_out, float *head_out, void *workspace,
+                        int64_t workspace_bytes, int32_t *status, void *stream) {
+    int rc;
+    if ((rc = admmnet_begin(cfg, B, workspace, workspace_bytes, status, stream))) return rc;
+    Ws ws;
+    carve_workspace(cfg, B, workspace, workspace_bytes, &ws, true);
+    hipStream_t st = (hipStream_t)stream;
+    for (int k = 0; k < cfg->K; ++k) {
+        if ((rc = admmnet_layer_front(cfg, W, k, y, b, sigma, B, workspace, ws.sum, status, stream))) return rc;
+        if (k < cfg->K - 1) {
+            if ((rc = launch_mean_from_sum(ws.sum, B, ws.mean, st))) return rc;
+            if ((rc = admmnet_layer_back(cfg, W, k, B, workspace, ws.mean, stream))) return rc;
+        }
+    }
+    return admmnet_finish(cfg, W, B, workspace, phi_out, head_out, stream);
+}
+
+int admmnet_glayer_f32(const admmnet_cfg *cfg, const float *lw, const void *phi, const float *h,
+                       const void *Z, int64_t B, void *G_out, float *w_out, float *rn_out, void *workspace,
+                       int64_t workspace_bytes, int32_t *status, void *stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (B < 1 || !lw || !phi || !h || !G_out || !workspace) {
+        set_error("glayer: bad argument");
+        return ADMMNET_E_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int D = cfg->M * cfg->N;
+    const int64_t n = D + 1;
+    // workspace: [rn scratch B floats | chunk buffers]; weights scalars are needed on the host
+    float sc[S_COUNT];
+    ADMM_HIP(hipMemcpyAsync(sc, lw, sizeof(sc), hipMemcpyDeviceToHost, st));
+    ADMM_HIP(hipStreamSynchronize(st));   // test/utility entry point only
+    admmnet_cfg c2 = *cfg;
+    Ws ws;
+    char *base = (char *)workspace;
+    const int64_t rn_bytes = align_up(sizeof(float) * B, 256);
+    if ((rc = carve_workspace(&c2, B, base + rn_bytes, workspace_bytes - rn_bytes, &ws, false))) return rc;
+    float *rn_tmp = (float *)base;
+    if (status) ADMM_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st));
+    for (int64_t b0 = 0; b0 < B; b0 += ws.chunk) {
+        const int64_t nb = (B - b0 < ws.chunk) ? (B - b0) : ws.chunk;
+        const float2 *ph = (const float2 *)phi + b0 * D;
+        const float2 *Zc = Z ? (const float2 *)Z + b0 * n * n : nullptr;
+        if ((rc = launch_build_block(D, nb, sc[S_CORNER_G], sc[S_INV_RHO_G], ph, h + b0 * D, Zc, ws, st))) return rc;
+        if ((rc = eig_chunk(D, nb, ws, status, st))) return rc;
+        if ((rc = launch_rebuild(D, nb, lw, ph, h + b0 * D, (float2 *)G_out + b0 * n * n,
+                                 rn_out ? rn_out + b0 : rn_tmp + b0, w_out ? w_out + b0 * n : nullptr, ws, st)))
+            return rc;
+    }
+    return ADMMNET_OK;
+}
+
+int64_t admmnet_eigh_workspace_bytes(int32_t n, int64_t B) {
+    if (n < 2 || n - 1 > kMaxD || B < 1) return -1;
+    admmnet_cfg cfg = {n - 1, 1, 3, 1, 0, 0, {0, 0}};
+    Ws ws;
+    carve_workspace(&cfg, B, nullptr, 0, &ws, false);
+    return ws.total_bytes;
+}
+
+int64_t admmnet_glayer_workspace_bytes(const admmnet_cfg *cfg, int64_t B) {
+    if (check_cfg(cfg) || B < 1) return -1;
+    Ws ws;
+    carve_workspace(cfg, B, nullptr, 0, &ws, false);
+    return ws.total_bytes + align_up(sizeof(float) * B, 256);
+}
+
+int admmnet_eigh_c64(int32_t n, int64_t B, const void *A, float *w, void *V, void *workspace,
+                     int64_t workspace_bytes, int32_t *status, void *stream) {
+    if (n < 2 || n - 1 > kMaxD || B < 1 || !A || !w || !V || !workspace) {
+        set_error("eigh: bad argument (n=%d)", n);
+        return ADMMNET_E_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    admmnet_cfg cfg = {n - 1, 1, 3, 1, 0, 0, {0, 0}};
+    Ws ws;
+    int rc;
+    if ((rc = carve_workspace(&cfg, B, workspace, workspace_bytes, &ws, false))) return rc;
+    if (status) ADMM_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st));
+    const int D = n - 1;
+    for (int64_t b0 = 0; b0 < B; b0 += ws.chunk) {
+        const int64_t nb = (B - b0 < ws.chunk) ? (B - b0) : ws.chunk;
+        if ((rc = launch_build_generic(n, nb, (const float2 *)A + b0 * n * n, ws, st))) return rc;
+        if ((rc = eig_chunk(D, nb, ws, status, st))) return rc;
+        if ((rc = launch_vout(n, nb, (float2 *)V + b0 * (int64_t)n * n, w + b0 * n, ws, st))) return rc;
+    }
+    return ADMMNET_OK;
+}
+
+int64_t admmnet_spectrum_workspace_bytes(int32_t xbase, int32_t ybase, int32_t nx, int32_t ny) {
+    if (xbase < 1 || ybase < 1 || nx < 1 || ny < 1) return -1;
+    return align_up(sizeof(double2) * (int64_t)nx * xbase, 256) + align_up(sizeof(double2) * (int64_t)ny * ybase, 256);
+}
+
+int admmnet_spectrum_f64(const void *phi, int64_t B, int32_t xbase, int32_t ybase, const double *taus,
+                         int32_t nx, const double *fs, int32_t ny, double *out, void *workspace,
+                         int64_t workspace_bytes, void *stream) {
+    const int64_t need = admmnet_spectrum_workspace_bytes(xbase, ybase, nx, ny);
+    if (need < 0 || B < 1 || !phi || !taus || !fs || !out || !workspace) {
+        set_error("spectrum: bad argument");
+        return ADMMNET_E_ARG;
+    }
+    if (workspace_bytes < need) {
+        set_error("spectrum: workspace too small");
+        return ADMMNET_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    double2 *tabD = (double2 *)workspace;
+    double2 *tabS = (double2 *)((char *)workspace + align_up(sizeof(double2) * (int64_t)nx * xbase, 256));
+    int rc;
+    if ((rc = launch_spectrum_tables(taus, nx, xbase, fs, ny, ybase, tabD, tabS, st))) return rc;
+    return launch_spectrum_main((const float2 *)phi, B, xbase, ybase, tabD, nx, tabS, ny, out, st);
+}
+
+}  // extern "C"

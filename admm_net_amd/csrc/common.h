@@ -1,0 +1,161 @@
+// common.h -- shared host/device declarations of the gfx950 ADMM-Net library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/admmnet.h"
+#include "eig_core.h"
+
+namespace admmnet {
+
+constexpr float kEpsRef = 1e-8f;   // epsilon of every reference layer (admm_net.py:74,114,211,360)
+constexpr int kHid = 64;           // HLayer.correction_net hidden width (admm_net.py:128)
+constexpr int kMaxD = 256;         // largest supported signal length D = M*N
+constexpr int kLogCapMul = 3;      // rotation-log capacity = kLogCapMul * n * n records per matrix
+
+void set_error(const char *fmt, ...);
+#define ADMM_HIP(call)                                                              \
+    do {                                                                            \
+        hipError_t _e = (call);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            admmnet::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), \
+                               __FILE__, __LINE__);                                 \
+            return ADMMNET_E_HIP;                                                   \
+        }                                                                           \
+    } while (0)
+
+// ---- packed per-layer weights (floats) -------------------------------------
+// scalars, resolved on the host by admmnet_pack_weights
+enum LayerScalar {
+    S_RHO_PHI = 0,    // softplus(phiLayers.k.rho)                      admm_net.py:97
+    S_RHO_H_EPS = 1,  // softplus(hLayers.k.rho) + eps                  admm_net.py:148,151
+    S_SIG_PW = 2,     // sigmoid(hLayers.k.projection_weight)          admm_net.py:188
+    S_CORNER_G = 3,   // 1 / (softplus(gLayers.k.lambda_param)^2 + eps) admm_net.py:269-271
+    S_INV_RHO_G = 4,  // 1 / (softplus(gLayers.k.rho) + eps)            admm_net.py:287-288
+    S_THR = 5,        // sigmoid(gLayers.k.threshold)                  admm_net.py:321
+    S_RHO_Z = 6,      // softplus(zLayers.k.rho)                        admm_net.py:406
+    S_CORNER_Z = 7,   // 1 / (softplus(zLayers.k.lambda_param)^2 + eps) admm_net.py:424-426
+    S_KNORM = 8,      // (float)(k / 10.0)                              admm_net.py:457
+    S_A_COEF = 9,     // 2 * sqrtf((float)(M*N))                        admm_net.py:159
+    S_COUNT = 16
+};
+
+struct LayerLayout {
+    int D;
+    __host__ __device__ int off_scal() const { return 0; }
+    __host__ __device__ int off_w1t() const { return S_COUNT; }               // [D][64]  (transposed correction_net.0.weight)
+    __host__ __device__ int off_b1() const { return off_w1t() + D * kHid; }   // [64]
+    __host__ __device__ int off_w2t() const { return off_b1() + kHid; }       // [64][D]  (transposed correction_net.2.weight)
+    __host__ __device__ int off_b2() const { return off_w2t() + kHid * D; }   // [D]
+    __host__ __device__ int off_vn() const { return off_b2() + D; }           // value_net: w1[16] b1[16] w2[16] b2[1]
+    __host__ __device__ int off_rs() const { return off_vn() + 49; }          // residual_scale_net: W1[32][3] b1[32] w2[32] b2[1]
+    __host__ __device__ int size() const { return (off_rs() + 161 + 3) & ~3; }
+};
+
+// head (PeakSearchLayer) packed layout, hidden = 128, heads = 4
+struct HeadLayout {
+    int D, L;
+    __host__ __device__ int off_pos() const { return 0; }                          // position_encoder [D][2]
+    __host__ __device__ int off_fe0w() const { return off_pos() + 2 * D; }         // [2D][128] transposed
+    __host__ __device__ int off_fe0b() const { return off_fe0w() + 2 * D * 128; }
+    __host__ __device__ int off_fe2w() const { return off_fe0b() + 128; }          // [128][128] transposed
+    __host__ __device__ int off_fe2b() const { return off_fe2w() + 128 * 128; }
+    __host__ __device__ int off_ppw() const { return off_fe2b() + 128; }           // position_projection.weight [128][2]
+    __host__ __device__ int off_ppb() const { return off_ppw() + 256; }
+    __host__ __device__ int off_inw() const { return off_ppb() + 128; }            // in_proj_weight [384][128] -> stored transposed [128][384]
+    __host__ __device__ int off_inb() const { return off_inw() + 384 * 128; }
+    __host__ __device__ int off_outw() const { return off_inb() + 384; }           // out_proj.weight transposed [128][128]
+    __host__ __device__ int off_outb() const { return off_outw() + 128 * 128; }
+    __host__ __device__ int off_pe0w() const { return off_outb() + 128; }          // [128][64] transposed
+    __host__ __device__ int off_pe0b() const { return off_pe0w() + 128 * 64; }
+    __host__ __device__ int off_pe2w() const { return off_pe0b() + 64; }           // [64][32] transposed
+    __host__ __device__ int off_pe2b() const { return off_pe2w() + 64 * 32; }
+    __host__ __device__ int off_pe4w() const { return off_pe2b() + 32; }           // [32][16] transposed
+    __host__ __device__ int off_pe4b() const { return off_pe4w() + 32 * 16; }
+    // per target t: tau.0 w[16][32]T b[32], tau.2 w[32] b[1], f.0 w[16][32]T b[32], f.2 w[32] b[1]
+    __host__ __device__ int off_reg(int t) const { return off_pe4b() + 16 + t * reg_size(); }
+    __host__ __device__ int reg_size() const { return 2 * (16 * 32 + 32 + 32 + 1); }
+    __host__ __device__ int off_conf() const { return off_reg(L); }                // c.0 w[16][16]T b[16], c.2 w[16] b[1]
+    __host__ __device__ int size() const { return (off_conf() + 16 * 16 + 16 + 16 + 1 + 3) & ~3; }
+};
+
+// ---- workspace carve (all offsets in bytes, 256-byte aligned) ------------
+struct Ws {
+    float2 *G, *Z;            // [B][n][n] state, original index order, full storage
+    float2 *phi[2];           // [B][D] double buffered (layer k uses k&1)
+    float *h[2];              // [B][D]
+    float *alpha;             // [B] adaptive step of the previous layer
+    float *rn;                // [B] ||G - C||_F of the current layer
+    double *sum;              // [2] scratch for the batch sum
+    float *mean;              // [1] batch mean (single-rank path)
+    float *headkv;            // [2][D][128] batch independent K / V projections of the head
+    // chunk-sized eigensolver buffers
+    float2 *Mbuf;             // [chunk][D*D + D + 1]: M row-major, arrow a[D], corner (re only)
+    float *QV;                // [chunk][n][2D] planar transposed: QT (D columns) then VT (n columns)
+    float *dT, *eT;           // [ceil(chunk/64)][n][64]
+    float *w, *w0;            // [chunk][n] eigenvalues, first row of W
+    LogRec *log;              // [chunk][cap + 16]
+    int *logn;                // [chunk][2]: records, status
+    int64_t chunk;            // signals per chunk
+    int64_t cap;              // log records per matrix (excluding the 16 pad records)
+    int64_t total_bytes;
+};
+
+int64_t eig_chunk_bytes(int D, int64_t chunk);
+int carve_workspace(const admmnet_cfg *cfg, int64_t B, void *base, int64_t bytes, Ws *ws, bool state);
+int64_t pick_chunk(const admmnet_cfg *cfg, int64_t B);
+
+// ---- kernel launchers (each enqueues on `st`, returns ADMMNET_* code) ----------
+// prep.hip
+int launch_prep(const admmnet_cfg *cfg, const float *lw, int k, const float2 *y, const float2 *b,
+                const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st);
+int launch_build_generic(int n, int64_t nb, const float2 *A, const Ws &ws, hipStream_t st);
+int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const float2 *phi, const float *h,
+                       const float2 *Z, const Ws &ws, hipStream_t st);
+// tridiag.hip
+int launch_tridiag(int D, int64_t nb, const Ws &ws, hipStream_t st);
+// tql.hip
+int launch_tql(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st);
+// rotapply.hip
+int launch_rotapply(int D, int64_t nb, const Ws &ws, hipStream_t st);
+// rebuild.hip
+int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h,
+                   float2 *G, float *rn, float *w_out, const Ws &ws, hipStream_t st);
+int launch_vout(int n, int64_t nb, float2 *V, float *w, const Ws &ws, hipStream_t st);
+// zstep.hip
+int launch_rn_sum(int64_t B, const float *rn, double *sum, hipStream_t st);
+int launch_mean_from_sum(const double *sum, int64_t B, float *mean, hipStream_t st);
+int launch_zstep(const float *lw, int D, int64_t B, const float *rn, const float *mean, float *alpha, hipStream_t st);
+// head.hip
+int launch_head(const admmnet_cfg *cfg, const float *hw, int64_t B, const float2 *phi, float *kv,
+                float *out, hipStream_t st);
+// spectrum.hip
+int launch_spectrum_tables(const double *taus, int nx, int xbase, const double *fs, int ny, int ybase,
+                           double2 *tabD, double2 *tabS, hipStream_t st);
+int launch_spectrum_main(const float2 *phi, int64_t B, int xbase, int ybase, const double2 *tabD, int nx,
+                         const double2 *tabS, int ny, double *out, hipStream_t st);
+
+// ---- small device helpers ---------------------------------------------------
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {  // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ float2 cmacc(float2 acc, float2 a, float2 b) {  // acc + conj(a) * b
+    acc.x = fmaf(a.x, b.x, fmaf(a.y, b.y, acc.x));
+    acc.y = fmaf(a.x, b.y, fmaf(-a.y, b.x, acc.y));
+    return acc;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace admmnet
