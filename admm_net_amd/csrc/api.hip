@@ -19,6 +19,29 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// ---- profiler -------------------------------------------------------------------
+static const int kProfMax = 8192;
+static bool g_prof_on = false;
+static int g_prof_n = 0;
+static hipEvent_t g_prof_ev[kProfMax][2];
+static int g_prof_class[kProfMax];
+static int g_prof_created = 0;
+
+ProfScope::ProfScope(int kclass, hipStream_t s) : slot(-1), st(s) {
+    if (!g_prof_on || g_prof_n >= kProfMax) return;
+    slot = g_prof_n++;
+    if (slot >= g_prof_created) {
+        (void)hipEventCreate(&g_prof_ev[slot][0]);
+        (void)hipEventCreate(&g_prof_ev[slot][1]);
+        g_prof_created = slot + 1;
+    }
+    g_prof_class[slot] = kclass;
+    (void)hipEventRecord(g_prof_ev[slot][0], st);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof_ev[slot][1], st);
+}
+
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 static int check_cfg(const admmnet_cfg *cfg) {
@@ -64,7 +87,7 @@ struct Carver {
 static void carve_chunk(Carver &c, int D, int64_t chunk, Ws *ws) {
     const int64_t n = D + 1;
     ws->chunk = chunk;
-    ws->cap = (int64_t)kLogCapMul * n * n;
+    ws->cap = ((int64_t)kLogCapMul * n * n + 64 * n + 64 + 7) & ~(int64_t)7;   // whole 64-byte groups
     ws->Mbuf = c.take<float2>(chunk * ((int64_t)D * D + D + 1));
     ws->QV = c.take<float>(chunk * n * 2 * D);
     const int64_t groups = (chunk + 63) / 64;
@@ -72,7 +95,7 @@ static void carve_chunk(Carver &c, int D, int64_t chunk, Ws *ws) {
     ws->eT = c.take<float>(groups * n * 64);
     ws->w = c.take<float>(chunk * n);
     ws->w0 = c.take<float>(chunk * n);
-    ws->log = c.take<LogRec>(chunk * (ws->cap + 16));
+    ws->log = c.take<LogRec>(chunk * ws->cap);
     ws->logn = c.take<int>(chunk * 2);
 }
 
@@ -427,6 +450,29 @@ int admmnet_eigh_c64(int32_t n, int64_t B, const void *A, float *w, void *V, voi
         if ((rc = eig_chunk(D, nb, ws, status, st))) return rc;
         if ((rc = launch_vout(n, nb, (float2 *)V + b0 * (int64_t)n * n, w + b0 * n, ws, st))) return rc;
     }
+    return ADMMNET_OK;
+}
+
+int admmnet_profile_enable(int32_t on) {
+    g_prof_on = on != 0;
+    g_prof_n = 0;
+    return ADMMNET_OK;
+}
+
+int admmnet_profile_read(double *ms_total, int64_t *launches, int32_t nclasses) {
+    if (!ms_total || !launches || nclasses < KC_COUNT) {
+        set_error("profile_read: need %d classes", (int)KC_COUNT);
+        return ADMMNET_E_ARG;
+    }
+    for (int i = 0; i < nclasses; ++i) { ms_total[i] = 0.0; launches[i] = 0; }
+    for (int i = 0; i < g_prof_n; ++i) {
+        ADMM_HIP(hipEventSynchronize(g_prof_ev[i][1]));
+        float ms = 0.f;
+        ADMM_HIP(hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]));
+        ms_total[g_prof_class[i]] += ms;
+        launches[g_prof_class[i]] += 1;
+    }
+    g_prof_n = 0;
     return ADMMNET_OK;
 }
 

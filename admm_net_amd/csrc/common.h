@@ -94,10 +94,10 @@ struct Ws {
     float *QV;                // [chunk][n][2D] planar transposed: QT (D columns) then VT (n columns)
     float *dT, *eT;           // [ceil(chunk/64)][n][64]
     float *w, *w0;            // [chunk][n] eigenvalues, first row of W
-    LogRec *log;              // [chunk][cap + 16]
+    LogRec *log;              // [chunk][cap], 64-byte groups (eig_core.h)
     int *logn;                // [chunk][2]: records, status
     int64_t chunk;            // signals per chunk
-    int64_t cap;              // log records per matrix (excluding the 16 pad records)
+    int64_t cap;              // log records per matrix (multiple of 8)
     int64_t total_bytes;
 };
 
@@ -134,6 +134,15 @@ int launch_spectrum_tables(const double *taus, int nx, int xbase, const double *
                            double2 *tabD, double2 *tabS, hipStream_t st);
 int launch_spectrum_main(const float2 *phi, int64_t B, int xbase, int ybase, const double2 *tabD, int nx,
                          const double2 *tabS, int ny, double *out, hipStream_t st);
+
+// ---- optional per-kernel-class HIP-event profiler (bench.py roofline leg) ------
+enum KernelClass { KC_PREP = 0, KC_TRIDIAG, KC_TQL, KC_ROTAPPLY, KC_REBUILD, KC_ZSTEP, KC_HEAD, KC_SPECTRUM, KC_COUNT };
+struct ProfScope {   // records start/stop events on `st` around a launcher body when profiling is on
+    int slot;
+    hipStream_t st;
+    ProfScope(int kclass, hipStream_t s);
+    ~ProfScope();
+};
 
 // ---- small device helpers ---------------------------------------------------
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {

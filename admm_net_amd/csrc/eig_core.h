@@ -22,14 +22,56 @@
 
 namespace admmnet {
 
-// One 8-byte record of the rotation log.  A QL sweep writes a header
-// {start plane i0 = m-1, count} followed by `count` rotations (c, s) for the
-// planes i0, i0-1, ..., i0-count+1 (plane i mixes columns i and i+1).
+// One 8-byte record of the rotation log.  Records come in 64-byte GROUPS of 8 so that the
+// replay kernel fetches one group with a single aligned s_load_dwordx16.  A QL sweep over the
+// planes i0 >= i >= l (plane i mixes columns i and i+1) writes
+//   1 header group : record 0 = {g_hi = i0 >> 3, g_lo = l >> 3}, records 1..7 unused
+//   g_hi - g_lo + 1 rotation groups, highest planes first: group g holds the planes
+//     8g+7, 8g+6, ..., 8g in that order; planes outside [l, i0] (or skipped by the underflow
+//     exit of the sweep) hold the identity rotation (c, s) = (1, 0).
 struct LogRec {
     union {
         struct { float c, s; } r;
-        struct { int32_t i0, cnt; } h;
+        struct { int32_t g_hi, g_lo; } h;
     };
+};
+
+// Log writer over a flat LogRec array (host model and device share it).
+struct LogWriter {
+    LogRec *lg;
+    int cap;   // records available
+    int pos;   // next free record (multiple of 8)
+    int cur;   // next rotation slot of the open sweep
+    int endp;  // one past the last slot of the open sweep
+    HD bool begin(int i0, int l) {
+        const int g_hi = i0 >> 3, g_lo = l >> 3;
+        const int need = 8 + 8 * (g_hi - g_lo + 1);
+        if (pos + need > cap) return false;
+        LogRec h;
+        h.h.g_hi = g_hi;
+        h.h.g_lo = g_lo;
+        lg[pos] = h;
+        cur = pos + 8;
+        endp = pos + need;
+        pos = endp;
+        LogRec id;
+        id.r.c = 1.0f;
+        id.r.s = 0.0f;
+        for (int i = 8 * g_hi + 7; i > i0; --i) lg[cur++] = id;   // planes above the window
+        return true;
+    }
+    HD void rot(float c, float s) {
+        LogRec r;
+        r.r.c = c;
+        r.r.s = s;
+        lg[cur++] = r;
+    }
+    HD void end() {   // identity for whatever is left (below the window / after an early exit)
+        LogRec id;
+        id.r.c = 1.0f;
+        id.r.s = 0.0f;
+        while (cur < endp) lg[cur++] = id;
+    }
 };
 
 constexpr float kEps32 = 5.9604645e-08f;  // 2^-24, unit roundoff of binary32
@@ -61,10 +103,10 @@ HD void householder_c(float ar, float ai, float xnorm2, float &beta, float &tr, 
 // real symmetric tridiagonal matrix; d[0..n-1] diagonal, e[i] couples i,i+1.
 // Accessors: D(i), E(i) return references; Z0(i) is a length-n row vector that
 // receives the same rotations (pass the first row of the identity to obtain
-// the first row of the eigenvector matrix W).  `emit(rec)` appends one LogRec
-// and returns false on overflow.  Returns 0 ok, 1 no convergence, 2 overflow.
-template <class DA, class EA, class ZA, class Emit, class Patch>
-HD int tql_lane(int n, DA D, EA E, ZA Z0, Emit emit, Patch patch, int max_sweeps, int &nsweeps) {
+// the first row of the eigenvector matrix W).  `log` is a LogWriter-like policy
+// (begin / rot / end).  Returns 0 ok, 1 no convergence, 2 log overflow.
+template <class DA, class EA, class ZA, class Log>
+HD int tql_lane(int n, DA D, EA E, ZA Z0, Log &log, int max_sweeps, int &nsweeps) {
     nsweeps = 0;
     for (int l = 0; l < n; ++l) {
         int iter = 0;
@@ -80,9 +122,7 @@ HD int tql_lane(int n, DA D, EA E, ZA Z0, Emit emit, Patch patch, int max_sweeps
                 float r = sqrtf(g * g + 1.0f);
                 g = D(m) - D(l) + E(l) / (g + sign_of(r, g));
                 float s = 1.0f, c = 1.0f, p = 0.0f;
-                int hdr = patch(-1, 0, 0);   // reserve header slot
-                if (hdr < 0) return 2;
-                int cnt = 0;
+                if (!log.begin(m - 1, l)) return 2;
                 int i;
                 bool brk = false;
                 for (i = m - 1; i >= l; --i) {
@@ -108,13 +148,9 @@ HD int tql_lane(int n, DA D, EA E, ZA Z0, Emit emit, Patch patch, int max_sweeps
                     float zi = Z0(i);
                     Z0(i + 1) = s * zi + c * zf;
                     Z0(i) = c * zi - s * zf;
-                    LogRec rec;
-                    rec.r.c = c;
-                    rec.r.s = s;
-                    if (!emit(rec)) return 2;
-                    ++cnt;
+                    log.rot(c, s);
                 }
-                patch(hdr, m - 1, cnt);
+                log.end();
                 ++nsweeps;
                 if (brk) continue;
                 D(l) -= p;
@@ -124,6 +160,102 @@ HD int tql_lane(int n, DA D, EA E, ZA Z0, Emit emit, Patch patch, int max_sweeps
         } while (m != l);
     }
     return 0;
+}
+
+// 1/sqrt(x): one v_rsq_f32 (1 ulp) + one Newton step on the device, exact on the host.
+HD float rsqrt_nr(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float y = __builtin_amdgcn_rsqf(x);
+    return y * fmaf(-0.5f * x * y, y, 1.5f);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+
+// Same algorithm as tql_lane, organised for the device: the rotation loop carries
+// (s, c, p, g) only through registers; d[i], e[i] of the NEXT plane are fetched one
+// iteration ahead, the tracked eigenvector row keeps its running element in a register,
+// and the square root / two divisions of the textbook recurrence become one reciprocal
+// square root.  `zc`-style carried values make every LDS access of an iteration independent
+// of the serial chain.
+template <class DA, class EA, class ZA, class Log>
+HD int tql_lane_pf(int n, DA D, EA E, ZA Z0, Log &log, int max_sweeps, int &nsweeps) {
+    nsweeps = 0;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0;
+        for (;;) {
+            int m = l;
+            for (; m < n - 1; ++m) {
+                const float dd = fabsf(D(m)) + fabsf(D(m + 1));
+                if (fabsf(E(m)) <= kEps32 * dd) break;
+            }
+            if (m == l) break;
+            if (iter++ >= max_sweeps) return 1;
+            const float dl = D(l), el = E(l);
+            float g = (D(l + 1) - dl) / (2.0f * el);
+            float r = sqrtf(g * g + 1.0f);
+            g = D(m) - dl + el / (g + sign_of(r, g));
+            float s = 1.0f, c = 1.0f, p = 0.0f;
+            if (!log.begin(m - 1, l)) return 2;
+            int i = m - 1;
+            float e_i = E(i), d_i = D(i), d_ip1 = D(m);
+            float zc = Z0(m);   // running element z[i+1]
+            bool brk = false;
+            for (; i >= l; --i) {
+                const int ip = (i > l) ? i - 1 : i;   // clamped prefetch index
+                const float e_nx = E(ip), d_nx = D(ip);
+                const float zi = Z0(i);
+                const float f = s * e_i, b = c * e_i;
+                const float rr = f * f + g * g;
+                if (rr == 0.0f) {      // underflow recovery of the textbook algorithm
+                    E(i + 1) = 0.0f;
+                    D(i + 1) = d_ip1 - p;
+                    E(m) = 0.0f;
+                    brk = true;
+                    break;
+                }
+                const float rinv = rsqrt_nr(rr);
+                E(i + 1) = rr * rinv;
+                s = f * rinv;
+                c = g * rinv;
+                g = d_ip1 - p;
+                const float t = (d_i - g) * s + 2.0f * c * b;
+                p = s * t;
+                D(i + 1) = g + p;
+                g = c * t - b;
+                Z0(i + 1) = s * zi + c * zc;
+                zc = c * zi - s * zc;
+                log.rot(c, s);
+                d_ip1 = d_i;
+                e_i = e_nx;
+                d_i = d_nx;
+            }
+            Z0(i + 1) = zc;   // i == l-1 after a full sweep, or the plane where it stopped
+            log.end();
+            ++nsweeps;
+            if (brk) continue;
+            D(l) = d_ip1 - p;   // d_ip1 holds the old d[l]
+            E(l) = g;
+            E(m) = 0.0f;
+        }
+    }
+    return 0;
+}
+
+// QL converges fast and accurately when the matrix is graded small -> large from top to
+// bottom (LAPACK csteqr picks QL or QR per block by comparing |d(l)| and |d(lend)|).  The
+// tridiagonalisation of the layer matrices starts at the arrow column, which puts the few
+// large entries FIRST, so instead of a second (QR) code path the tridiagonal matrix is
+// reversed (T' = J T J, W' = J W): returns true when the top half carries more weight.
+template <class DA, class EA>
+HD bool choose_flip(int n, DA D, EA E) {
+    float top = 0.f, bot = 0.f;
+    const int hlf = n / 2;
+    for (int i = 0; i < hlf; ++i) {
+        top += fabsf(D(i)) + fabsf(E(i));
+        bot += fabsf(D(n - 1 - i)) + (n - 2 - i >= 0 ? fabsf(E(n - 2 - i)) : 0.f);
+    }
+    return top > bot;
 }
 
 // torch.nn.functional.softplus (beta = 1, threshold = 20)

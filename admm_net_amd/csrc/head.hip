@@ -151,6 +151,7 @@ __global__ __launch_bounds__(HH) void head_kernel(int D, int L, const float *__r
 
 int launch_head(const admmnet_cfg *cfg, const float *hw, int64_t B, const float2 *phi, float *kv,
                 float *out, hipStream_t st) {
+    ProfScope _prof(KC_HEAD, st);
     if (B <= 0) return ADMMNET_OK;
     const int D = cfg->M * cfg->N, L = cfg->L;
     hipLaunchKernelGGL(headkv_kernel, dim3(D), dim3(HH), 0, st, D, L, hw, kv);

@@ -223,6 +223,7 @@ int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const flo
 
 int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2 *y, const float2 *b,
                 const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st) {
+    ProfScope _prof(KC_PREP, st);
     if (nb <= 0) return ADMMNET_OK;
     const int D = cfg->M * cfg->N, n = D + 1;
     const LayerLayout L{D};

@@ -171,6 +171,7 @@ __global__ void vout_kernel(int n, const float *__restrict__ QV, const float *__
 
 int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G,
                    float *rn, float *w_out, const Ws &ws, hipStream_t st) {
+    ProfScope _prof(KC_REBUILD, st);
     if (nb <= 0) return ADMMNET_OK;
     const int n = D + 1;
     const size_t lds = sizeof(float) * (2 * ((n + 4) & ~3) + 2 * D + 8);

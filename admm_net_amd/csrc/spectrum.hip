@@ -85,6 +85,7 @@ int launch_spectrum_tables(const double *taus, int nx, int xbase, const double *
 
 int launch_spectrum_main(const float2 *phi, int64_t B, int xbase, int ybase, const double2 *tabD, int nx,
                          const double2 *tabS, int ny, double *out, hipStream_t st) {
+    ProfScope _prof(KC_SPECTRUM, st);
     if (B <= 0) return ADMMNET_OK;
     const size_t lds = sizeof(double2) * ((size_t)xbase * ybase + (size_t)ybase * SP_XCHUNK);
     if (lds > 150 * 1024) {

@@ -245,6 +245,7 @@ static size_t td_lds_bytes(int D, bool ldsm) {
 }
 
 int launch_tridiag(int D, int64_t nb, const Ws &ws, hipStream_t st) {
+    ProfScope _prof(KC_TRIDIAG, st);
     if (D < 1 || D > kMaxD) {
         set_error("tridiag: D=%d unsupported (1..%d)", D, kMaxD);
         return ADMMNET_E_ARG;

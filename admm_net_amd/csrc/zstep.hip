@@ -63,6 +63,7 @@ int launch_mean_from_sum(const double *sum, int64_t B, float *mean, hipStream_t 
 
 int launch_zstep(const float *lw, int D, int64_t B, const float *rn, const float *mean, float *alpha,
                  hipStream_t st) {
+    ProfScope _prof(KC_ZSTEP, st);
     if (B <= 0) return ADMMNET_OK;
     hipLaunchKernelGGL(zstep_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, D, B, lw, rn, mean,
                        alpha);

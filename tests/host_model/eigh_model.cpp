@@ -12,7 +12,11 @@
 using cf = std::complex<float>;
 using namespace admmnet;
 
+static int g_variant = 1;
+
 extern "C" {
+
+void hm_set_variant(int v) { g_variant = v; }
 
 // A: n x n row-major Hermitian (lower triangle read).  Outputs d[n], e[n] (e[n-1]=0),
 // Q n x n row-major explicit unitary with A = Q T Q^H.
@@ -78,27 +82,14 @@ int hm_tridiag(int n, const cf *Ain, float *d, float *e, cf *Q) {
 
 // d,e in/out (d -> eigenvalues), z0[n] in/out, log[cap] records, returns status.
 int hm_tql(int n, float *d, float *e, float *z0, LogRec *log, int cap, int *nrec, int *nsweeps) {
-    int pos = 0;
     auto D = [&](int i) -> float & { return d[i]; };
     auto E = [&](int i) -> float & { return e[i]; };
     auto Z = [&](int i) -> float & { return z0[i]; };
-    auto emit = [&](const LogRec &r) -> bool {
-        if (pos >= cap) return false;
-        log[pos++] = r;
-        return true;
-    };
-    auto patch = [&](int at, int i0, int cnt) -> int {
-        if (at < 0) {
-            if (pos >= cap) return -1;
-            return pos++;
-        }
-        log[at].h.i0 = i0;
-        log[at].h.cnt = cnt;
-        return at;
-    };
+    LogWriter lw{log, cap, 0, 0, 0};
     int ns = 0;
-    int st = tql_lane(n, D, E, Z, emit, patch, 60, ns);
-    *nrec = pos;
+    // g_variant 0: textbook organisation (tql_lane); 1: the prefetching variant the device runs
+    int st = g_variant ? tql_lane_pf(n, D, E, Z, lw, 60, ns) : tql_lane(n, D, E, Z, lw, 60, ns);
+    *nrec = lw.pos;
     *nsweeps = ns;
     return st;
 }
@@ -107,17 +98,20 @@ int hm_tql(int n, float *d, float *e, float *z0, LogRec *log, int cap, int *nrec
 void hm_replay(int n, int rows, float *X, const LogRec *log, int nrec) {
     int pos = 0;
     while (pos < nrec) {
-        int i0 = log[pos].h.i0, cnt = log[pos].h.cnt;
-        ++pos;
-        for (int t = 0; t < cnt; ++t) {
-            int i = i0 - t;
-            float c = log[pos].r.c, s = log[pos].r.s;
-            ++pos;
-            for (int r = 0; r < rows; ++r) {
-                float *z = X + (size_t)r * n;
-                float f = z[i + 1];
-                z[i + 1] = s * z[i] + c * f;
-                z[i] = c * z[i] - s * f;
+        const int g_hi = log[pos].h.g_hi, g_lo = log[pos].h.g_lo;
+        pos += 8;
+        for (int g = g_hi; g >= g_lo; --g) {
+            for (int t = 0; t < 8; ++t) {
+                const int i = 8 * g + 7 - t;
+                const float c = log[pos].r.c, s = log[pos].r.s;
+                ++pos;
+                if (i + 1 >= n) continue;   // slot above the matrix: always identity
+                for (int r = 0; r < rows; ++r) {
+                    float *z = X + (size_t)r * n;
+                    float f = z[i + 1];
+                    z[i + 1] = s * z[i] + c * f;
+                    z[i] = c * z[i] - s * f;
+                }
             }
         }
     }
@@ -128,25 +122,42 @@ int hm_eigh(int n, const cf *A, float *w, cf *V, int *nrec_out, int *nsweeps_out
     std::vector<float> d(n), e(n), z0(n, 0.f);
     std::vector<cf> Q((size_t)n * n);
     hm_tridiag(n, A, d.data(), e.data(), Q.data());
-    int cap = 4 * n * n + 64;
+    int cap = (3 * n * n + 64 * n + 64 + 7) & ~7;   // = the device's capacity (api.hip carve_chunk)
     std::vector<LogRec> log(cap);
     int nrec = 0, ns = 0;
-    z0[0] = 1.f;
-    int st = hm_tql(n, d.data(), e.data(), z0.data(), log.data(), cap, &nrec, &ns);
+    auto Dg = [&](int i) -> float { return d[i]; };
+    auto Eg = [&](int i) -> float { return e[i]; };
+    const bool flip0 = choose_flip(n, Dg, Eg);
+    std::vector<float> dd(n), ee(n);
+    int st = 1;
+    bool flip = flip0;
+    for (int attempt = 0; attempt < 2 && st != 0; ++attempt) {
+        flip = flip0 ^ (attempt == 1);
+        for (int i = 0; i < n; ++i) {
+            dd[i] = d[flip ? n - 1 - i : i];
+            ee[i] = (i < n - 1) ? (flip ? e[n - 2 - i] : e[i]) : 0.f;
+            z0[i] = (i == (flip ? n - 1 : 0)) ? 1.f : 0.f;
+        }
+        st = hm_tql(n, dd.data(), ee.data(), z0.data(), log.data(), cap, &nrec, &ns);
+    }
+    d = dd;
     if (nrec_out) *nrec_out = nrec;
     if (nsweeps_out) *nsweeps_out = ns;
     if (st) return st;
-    // rows of Q as 2n real rows
+    // rows of Q (columns reversed when flipped) as 2n real rows
     std::vector<float> X((size_t)2 * n * n);
     for (int r = 0; r < n; ++r)
         for (int c = 0; c < n; ++c) {
-            X[(size_t)r * n + c] = Q[r * n + c].real();
-            X[(size_t)(n + r) * n + c] = Q[r * n + c].imag();
+            const int sc = flip ? n - 1 - c : c;
+            X[(size_t)r * n + c] = Q[r * n + sc].real();
+            X[(size_t)(n + r) * n + c] = Q[r * n + sc].imag();
         }
     hm_replay(n, 2 * n, X.data(), log.data(), nrec);
     for (int r = 0; r < n; ++r)
         for (int c = 0; c < n; ++c) V[r * n + c] = cf(X[(size_t)r * n + c], X[(size_t)(n + r) * n + c]);
-    // row 0 of V must equal z0 (first row of W): checked by the test through V itself
+    // consistency of the separately tracked first row of W with row 0 of V (Q row 0 = e_0)
+    for (int c = 0; c < n; ++c)
+        if (std::abs(V[c].real() - z0[c]) > 1e-4f || std::abs(V[c].imag()) > 1e-4f) return 7;
     for (int c = 0; c < n; ++c) w[c] = d[c];
     return 0;
 }
