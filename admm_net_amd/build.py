@@ -13,10 +13,13 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadmmnet_hip.so")
-SOURCES = ["api.hip", "prep.hip", "tridiag.hip", "tql.hip", "rotapply.hip", "rebuild.hip",
+SOURCES = ["api.hip", "prep.hip", "tridiag.hip", "tridiag_reg.hip", "tql.hip", "rotapply.hip", "rebuild.hip",
            "zstep.hip", "head.hip", "spectrum.hip"]
 HEADERS = ["common.h", "eig_core.h", os.path.join("..", "..", "include", "admmnet.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-file extras: the SLP vectoriser packs the rotation replay into v_pk_* ops that need a
+# register shuffle per plane (7 VALU per rotation instead of 4)
+EXTRA_FLAGS = {"rotapply.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -43,7 +46,7 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)

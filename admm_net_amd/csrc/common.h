@@ -92,7 +92,7 @@ struct Ws {
     // chunk-sized eigensolver buffers
     float2 *Mbuf;             // [chunk][D*D + D + 1]: M row-major, arrow a[D], corner (re only)
     float *QV;                // [chunk][n][2D] planar transposed: QT (D columns) then VT (n columns)
-    float *dT, *eT;           // [ceil(chunk/64)][n][64]
+    float *dT, *eT;           // [chunk][n] tridiagonal (diagonal, off-diagonal)
     float *w, *w0;            // [chunk][n] eigenvalues, first row of W
     LogRec *log;              // [chunk][cap], 64-byte groups (eig_core.h)
     int *logn;                // [chunk][2]: records, status
@@ -114,6 +114,7 @@ int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const flo
                        const float2 *Z, const Ws &ws, hipStream_t st);
 // tridiag.hip
 int launch_tridiag(int D, int64_t nb, const Ws &ws, hipStream_t st);
+int launch_tridiag_reg(int D, int64_t nb, const Ws &ws, hipStream_t st);   // tridiag_reg.hip, D <= 128
 // tql.hip
 int launch_tql(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st);
 // rotapply.hip

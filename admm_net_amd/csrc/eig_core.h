@@ -162,33 +162,73 @@ HD int tql_lane(int n, DA D, EA E, ZA Z0, Log &log, int max_sweeps, int &nsweeps
     return 0;
 }
 
-// 1/sqrt(x): one v_rsq_f32 (1 ulp) + one Newton step on the device, exact on the host.
-HD float rsqrt_nr(float x) {
+// 1/sqrt(x): one v_rsq_f32 (1 ulp) on the device, 1/sqrtf on the host.
+HD float rsqrt_fast(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    float y = __builtin_amdgcn_rsqf(x);
-    return y * fmaf(-0.5f * x * y, y, 1.5f);
+    return __builtin_amdgcn_rsqf(x);
 #else
     return 1.0f / sqrtf(x);
 #endif
 }
 
-// Same algorithm as tql_lane, organised for the device: the rotation loop carries
-// (s, c, p, g) only through registers; d[i], e[i] of the NEXT plane are fetched one
-// iteration ahead, the tracked eigenvector row keeps its running element in a register,
-// and the square root / two divisions of the textbook recurrence become one reciprocal
-// square root.  `zc`-style carried values make every LDS access of an iteration independent
-// of the serial chain.
-template <class DA, class EA, class ZA, class Log>
+// Bit set over the off-diagonal indices: bit j <=> e[j] is negligible.  Lets the QL driver find
+// the end of the current unreduced block in O(1) instead of re-scanning e[l..] before every
+// sweep (that scan is as long as the sweep itself).  Up to 64*MW indices.
+template <int MW>
+struct NegMask {
+    uint64_t w[MW];
+    HD void clear() {
+#pragma unroll
+        for (int k = 0; k < MW; ++k) w[k] = 0;
+    }
+    HD void put(int j, bool v) {   // branch free and fully unrolled so that w[] stays in registers
+        const uint64_t bit = (uint64_t)1 << (j & 63);
+        const int wi = j >> 6;
+#pragma unroll
+        for (int k = 0; k < MW; ++k) {
+            const uint64_t sel = (k == wi) ? bit : 0;
+            w[k] = (w[k] & ~sel) | (v ? sel : 0);
+        }
+    }
+    HD int first_from(int l) const {   // smallest set index >= l (one always exists: the sentinel)
+        int best = 64 * MW;
+#pragma unroll
+        for (int k = MW - 1; k >= 0; --k) {
+            const int lo = 64 * k;
+            uint64_t x = w[k];
+            if (l > lo) x = (l - lo >= 64) ? 0 : (x & (~(uint64_t)0 << (l - lo)));
+            if (x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                best = lo + (int)__builtin_ctzll(x);
+#else
+                best = lo + __builtin_ctzll(x);
+#endif
+            }
+        }
+        return best;
+    }
+};
+
+// Same algorithm as tql_lane, organised for the device:
+//  * the rotation loop carries (s, c, p, g) only through registers; d[i], e[i] of the NEXT plane
+//    are fetched one iteration ahead and the tracked eigenvector row keeps its running element in
+//    a register, so no LDS access sits on the serial chain;
+//  * sqrt + two divisions become one reciprocal square root followed by a first-order
+//    renormalisation of (c, s): the plane rotation stays orthogonal to O(eps^2), which matters
+//    because a biased |c|^2+|s|^2 accumulates linearly over the ~3n rotations a row sees;
+//  * the deflation test of every new off-diagonal is made inside the sweep and kept in a bit
+//    set (NegMask), replacing the O(n) scan before each sweep.
+template <int MW, class DA, class EA, class ZA, class Log>
 HD int tql_lane_pf(int n, DA D, EA E, ZA Z0, Log &log, int max_sweeps, int &nsweeps) {
     nsweeps = 0;
+    NegMask<MW> neg;
+    neg.clear();
+    for (int j = 0; j < n - 1; ++j) neg.put(j, fabsf(E(j)) <= kEps32 * (fabsf(D(j)) + fabsf(D(j + 1))));
+    neg.put(n - 1, true);   // sentinel: the block always ends at n-1
     for (int l = 0; l < n; ++l) {
         int iter = 0;
         for (;;) {
-            int m = l;
-            for (; m < n - 1; ++m) {
-                const float dd = fabsf(D(m)) + fabsf(D(m + 1));
-                if (fabsf(E(m)) <= kEps32 * dd) break;
-            }
+            const int m = neg.first_from(l);
             if (m == l) break;
             if (iter++ >= max_sweeps) return 1;
             const float dl = D(l), el = E(l);
@@ -199,7 +239,8 @@ HD int tql_lane_pf(int n, DA D, EA E, ZA Z0, Log &log, int max_sweeps, int &nswe
             if (!log.begin(m - 1, l)) return 2;
             int i = m - 1;
             float e_i = E(i), d_i = D(i), d_ip1 = D(m);
-            float zc = Z0(m);   // running element z[i+1]
+            float zc = Z0(m);        // running element z[i+1]
+            float dnew_up = 0.0f;    // new d[i+2]
             bool brk = false;
             for (; i >= l; --i) {
                 const int ip = (i > l) ? i - 1 : i;   // clamped prefetch index
@@ -211,18 +252,25 @@ HD int tql_lane_pf(int n, DA D, EA E, ZA Z0, Log &log, int max_sweeps, int &nswe
                     E(i + 1) = 0.0f;
                     D(i + 1) = d_ip1 - p;
                     E(m) = 0.0f;
+                    neg.put(i + 1, true);
                     brk = true;
                     break;
                 }
-                const float rinv = rsqrt_nr(rr);
-                E(i + 1) = rr * rinv;
-                s = f * rinv;
-                c = g * rinv;
+                const float rinv = rsqrt_fast(rr);
+                const float e_new = rr * rinv;   // new e[i+1]
+                E(i + 1) = e_new;
+                float s0 = f * rinv, c0 = g * rinv;
+                const float h = 0.5f * fmaf(-s0, s0, fmaf(-c0, c0, 1.0f));
+                s = fmaf(h, s0, s0);
+                c = fmaf(h, c0, c0);
                 g = d_ip1 - p;
                 const float t = (d_i - g) * s + 2.0f * c * b;
                 p = s * t;
-                D(i + 1) = g + p;
+                const float dnew = g + p;        // new d[i+1]
+                D(i + 1) = dnew;
                 g = c * t - b;
+                if (i + 1 < m) neg.put(i + 1, fabsf(e_new) <= kEps32 * (fabsf(dnew) + fabsf(dnew_up)));
+                dnew_up = dnew;
                 Z0(i + 1) = s * zi + c * zc;
                 zc = c * zi - s * zc;
                 log.rot(c, s);
@@ -233,10 +281,17 @@ HD int tql_lane_pf(int n, DA D, EA E, ZA Z0, Log &log, int max_sweeps, int &nswe
             Z0(i + 1) = zc;   // i == l-1 after a full sweep, or the plane where it stopped
             log.end();
             ++nsweeps;
-            if (brk) continue;
-            D(l) = d_ip1 - p;   // d_ip1 holds the old d[l]
+            if (brk) {
+                // e[m] was zeroed; re-test the untouched entries below the exit plane conservatively
+                for (int j = l; j <= i; ++j)
+                    neg.put(j, fabsf(E(j)) <= kEps32 * (fabsf(D(j)) + fabsf(D(j + 1))));
+                continue;
+            }
+            const float dl_new = d_ip1 - p;   // d_ip1 holds the old d[l]
+            D(l) = dl_new;
             E(l) = g;
             E(m) = 0.0f;
+            neg.put(l, fabsf(g) <= kEps32 * (fabsf(dl_new) + fabsf(dnew_up)));
         }
     }
     return 0;

@@ -5,22 +5,46 @@
 // one real row (re or im part of a row of Q) and keeps all n entries in
 // registers for the whole replay -- zero LDS, zero cross-lane traffic, the
 // rotation coefficients arrive as wave-uniform scalars (one aligned
-// s_load_dwordx16 per group of 8 planes, SGPR operands of the VALU ops).
-// The register array must be statically indexed, hence the replay is fully
-// unrolled over the plane index in groups of 8; a sweep enters only the
-// groups [g_lo, g_hi] named by its header, and the log pads the partial groups
-// with identity rotations so that no per-plane predicate is needed.
+// s_load_dwordx16 per 64-byte log group, SGPR operands of the VALU ops).
+// The register array must be statically indexed, so a sweep walks a fully
+// unrolled chain over the group number and enters the groups [g_lo, g_hi] its
+// header names; the log pads partial groups with identity rotations, so there is no per-plane
+// predicate.  The log is consumed as a flat stream of groups (sweep headers
+// included) with the next two groups always in flight in SGPRs, which hides
+// the scalar-load latency at 3 waves per SIMD.  (A switch(g) inside a loop was
+// tried instead of the unrolled if-chain: the merge of 129 live values doubled
+// the VGPR count and cost two thirds of the occupancy.)
 // This is the "apply Givens rotations" half of csteqr for the eigenvector
 // matrix consumed by /root/reference/admm_net.py:303,349.
 #include "common.h"
 
 namespace admmnet {
 
+struct Grp {   // one 64-byte log group: 8 records (c, s) or a header in record 0
+    float2 r[8];
+};
+
+template <int NMAX>
+__device__ __forceinline__ void rot8(float (&z)[NMAX], const Grp &q, const int G) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int i = 8 * G + 7 - t;
+        if (i + 1 < NMAX) {   // static: planes above the register array hold identity
+            const float c = q.r[t].x, s = q.r[t].y;
+            const float f = z[i + 1];
+            const float zi = z[i];
+            z[i + 1] = fmaf(s, zi, c * f);
+            z[i] = fmaf(c, zi, -(s * f));
+        }
+    }
+}
+
 template <int NMAX>
 __global__ __launch_bounds__(64) void rotapply_kernel(int D, float *__restrict__ QV,
                                                       const LogRec *__restrict__ log,
                                                       const int *__restrict__ logn, int64_t cap) {
-    constexpr int NG = (NMAX - 1 + 7) / 8;   // plane groups; planes 0 .. NMAX-2
     const int n = D + 1;
     const int64_t b = blockIdx.x;
     const int rho = blockIdx.y * 64 + threadIdx.x;
@@ -36,37 +60,34 @@ __global__ __launch_bounds__(64) void rotapply_kernel(int D, float *__restrict__
         z[j] = (c >= 0 && c < D && valid) ? q[(int64_t)c * 2 * D + rho] : 0.f;
     }
 
-    const int nrec = __builtin_amdgcn_readfirstlane(logn[b * 2]);
-    const LogRec *lgb = log + b * cap;
-    const int2 *lg = reinterpret_cast<const int2 *>(lgb);
-    const float2 *lgf = reinterpret_cast<const float2 *>(lgb);
-    int pos = 0;
-    while (pos < nrec) {
-        const int2 hdr = lg[pos];
-        const int g_hi = __builtin_amdgcn_readfirstlane(hdr.x);
-        const int g_lo = __builtin_amdgcn_readfirstlane(hdr.y);
-        const float2 *rp = lgf + pos + 8;   // group g starts at rp + 8 * (g_hi - g)
+    constexpr int NG = (NMAX - 1 + 7) / 8;   // plane groups; planes 0 .. NMAX-2
+    const int ngrp = __builtin_amdgcn_readfirstlane(logn[b * 2]) >> 3;
+    const Grp *lg = reinterpret_cast<const Grp *>(log + b * cap);
+    if (ngrp > 0) {
+        const int last = ngrp - 1;
+        // flat stream of 64-byte groups with the next two always in flight
+        Grp cur = lg[0], n1 = lg[min(1, last)], n2 = lg[min(2, last)];
+        int idx = 0;
+        while (idx < ngrp) {
+            // `cur` is a sweep header
+            const int g_hi = __float_as_int(cur.r[0].x);
+            const int g_lo = __float_as_int(cur.r[0].y);
+            cur = n1;
+            n1 = n2;
+            n2 = lg[min(idx + 3, last)];
+            ++idx;
 #pragma unroll
-        for (int g = NG - 1; g >= 0; --g) {
-            if (g <= g_hi && g >= g_lo) {
-                const float2 *gp = rp + 8 * (g_hi - g);
-                float2 cs[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) cs[t] = gp[t];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int i = 8 * g + 7 - t;
-                    if (i + 1 < NMAX) {   // static: planes above the register array hold identity
-                        const float c = cs[t].x, s = cs[t].y;
-                        const float f = z[i + 1];
-                        const float zi = z[i];
-                        z[i + 1] = s * zi + c * f;
-                        z[i] = c * zi - s * f;
-                    }
+            for (int g = NG - 1; g >= 0; --g) {
+                if (g <= g_hi && g >= g_lo) {
+                    const Grp n3 = lg[min(idx + 3, last)];
+                    rot8<NMAX>(z, cur, g);
+                    cur = n1;
+                    n1 = n2;
+                    n2 = n3;
+                    ++idx;
                 }
             }
         }
-        pos += 8 + 8 * (g_hi - g_lo + 1);
     }
     if (valid) {
 #pragma unroll

@@ -14,6 +14,9 @@
 // 160 KB gfx950 LDS); every access walks a column of the row-major image with
 // consecutive lanes on consecutive columns, so ds_read_b64 is conflict-free.
 // Larger D uses the same code on the global (L2 / Infinity Cache) image.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace admmnet {
@@ -75,8 +78,8 @@ __global__ __launch_bounds__(TD_THREADS) void tridiag_kernel(int D, float2 *__re
     for (int i = tid; i < D; i += TD_THREADS) v0s[i] = ag[i];
     __syncthreads();
 
-    float *dcol = dT + ((b >> 6) * n) * 64 + (b & 63);
-    float *ecol = eT + ((b >> 6) * n) * 64 + (b & 63);
+    float *dcol = dT + b * n;
+    float *ecol = eT + b * n;
 
     for (int r = 0; r < D; ++r) {
         // ---- reflector r: from the arrow (r == 0) or column r-1 of M, rows r..D-1
@@ -101,8 +104,8 @@ __global__ __launch_bounds__(TD_THREADS) void tridiag_kernel(int D, float2 *__re
         const float2 tau = make_float2(tr, ti);
         const float2 sc = make_float2(sr, si);
         if (tid == 0) {
-            ecol[r * 64] = beta;
-            dcol[r * 64] = (r == 0) ? ag[D].x : M[(r - 1) * P + r - 1].x;
+            ecol[r] = beta;
+            dcol[r] = (r == 0) ? ag[D].x : M[(r - 1) * P + r - 1].x;
             taus[r] = tau;
         }
         for (int i = r + tid; i < D; i += TD_THREADS) {
@@ -172,8 +175,8 @@ __global__ __launch_bounds__(TD_THREADS) void tridiag_kernel(int D, float2 *__re
         __syncthreads();
     }
     if (tid == 0) {
-        dcol[D * 64] = M[(D - 1) * P + D - 1].x;
-        ecol[D * 64] = 0.f;
+        dcol[D] = M[(D - 1) * P + D - 1].x;
+        ecol[D] = 0.f;
     }
     __syncthreads();
 
@@ -251,6 +254,14 @@ int launch_tridiag(int D, int64_t nb, const Ws &ws, hipStream_t st) {
         return ADMMNET_E_ARG;
     }
     if (nb <= 0) return ADMMNET_OK;
+    // D <= 128: register-resident kernel (tridiag_reg.hip).  ADMMNET_TRIDIAG=lds keeps the
+    // LDS-resident version below selectable for A/B runs; it also serves 128 < D <= 256 (global image).
+    static int use_lds = -1;
+    if (use_lds < 0) {
+        const char *e = getenv("ADMMNET_TRIDIAG");
+        use_lds = (e && !strcmp(e, "lds")) ? 1 : 0;
+    }
+    if (D <= 128 && !use_lds) return launch_tridiag_reg(D, nb, ws, st);
     const bool ldsm = td_lds_bytes(D, true) <= 160 * 1024;
     const size_t lds = td_lds_bytes(D, ldsm);
     if (ldsm) {

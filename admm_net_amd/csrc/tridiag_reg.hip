@@ -1,0 +1,298 @@
+// tridiag_reg.hip -- K1 for D <= 128: Householder tridiagonalisation + explicit Q with the
+// matrix held IN REGISTERS (LDS only carries vectors).
+//
+// A 256-thread workgroup owns one matrix.  Thread (ti, tj) = (tid >> 4, tid & 15) holds the
+// 2D-cyclic slice  m[a][b] = M[16 a + ti][16 b + tj]  (NA x NA complex, 128 VGPRs at NA = 8), so
+//   * the work stays balanced while the active trailing block shrinks (a cyclic slice of it);
+//   * every reduction the algorithm needs runs along tj = the 16 fast lanes of a DPP row
+//     (4 row_ror adds, no LDS, no barrier);
+//   * LDS per matrix is ~5 KB, so two workgroups share a CU and hide each other's latencies
+//     (the LDS-resident version in tridiag.hip needs 140 KB and a barrier-bound 512 threads).
+// Per reflector: 2 barriers (column broadcast, p / dot broadcast).  The explicit Q is
+// accumulated afterwards as P = Q^H (P <- P H^H), which puts ITS reduction on the fast lanes
+// too and needs no barrier at all.  Same mathematics as tridiag.hip / LAPACK chetd2 + cung2l
+// (first half of torch.linalg.eigh, /root/reference/admm_net.py:303).
+#include "common.h"
+
+namespace admmnet {
+
+constexpr int TR_THREADS = 256;
+
+// sum over the 16 lanes of a DPP row; every lane of the row receives the total
+__device__ __forceinline__ float row16_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xF, 0xF, false));
+    return x;
+}
+
+// Shared state of one workgroup's LDS vectors.
+template <int NA>
+struct TrShared {
+    float2 colbuf[2][16 * NA];
+    float2 pbuf[2][16 * NA];
+    float2 dotbuf[2][4];
+    float2 taus[16 * NA];
+};
+
+// One Householder step with the unit entry at index u, for 16*A0 <= u < 16*(A0+1): every loop over
+// the cyclic blocks starts at the compile-time bound A0, so the work shrinks with the trailing block
+// (a run-time bound turned into select instructions and kept the full 8 x 8 cost per step).
+template <int NA, int A0>
+__device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, int u, int D, float corner,
+                                        const float2 *__restrict__ ag, float2 *__restrict__ Mg,
+                                        float *__restrict__ dcol, float *__restrict__ ecol) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tj = tid & 15, ti = tid >> 4;
+    const int par = u & 1;
+    if (u == 0) {
+        for (int i = tid; i < 16 * NA; i += TR_THREADS) sh.colbuf[0][i] = (i < D) ? ag[i] : make_float2(0.f, 0.f);
+    } else {
+        const int k = u - 1;
+        if (tj == (k & 15)) {
+            // column k lives in block (k >> 4), which is A0 or (for u = 16 A0) A0 - 1
+            if ((k >> 4) == A0) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a) sh.colbuf[par][16 * a + ti] = m[a][A0];
+            } else {
+#pragma unroll
+                for (int a = 0; a < NA; ++a) sh.colbuf[par][16 * a + ti] = m[a][A0 > 0 ? A0 - 1 : 0];
+            }
+        }
+    }
+    __syncthreads();   // (A) column visible
+    const float2 *col = sh.colbuf[par];
+    float pn = 0.f;
+    for (int i = u + 1 + lane; i < D; i += 64) {
+        const float2 x = col[i];
+        pn += x.x * x.x + x.y * x.y;
+    }
+    const float xn2 = wave_sum(pn);
+    const float2 alpha = col[u];
+    float beta, tr, tim, sr, si;
+    householder_c(alpha.x, alpha.y, xn2, beta, tr, tim, sr, si);
+    const float2 tau = make_float2(tr, tim), sc = make_float2(sr, si);
+    if (tid == 0) {
+        ecol[u] = beta;
+        dcol[u] = (u == 0) ? corner : col[u - 1].x;
+        sh.taus[u] = tau;
+    }
+    // v restricted to my rows / my columns (zero above the unit position and beyond D)
+    float2 vr[NA], vc[NA];
+#pragma unroll
+    for (int a = A0; a < NA; ++a) {
+        const int i = 16 * a + ti;
+        float2 x = (i > u && i < D) ? cmul(col[i], sc) : make_float2(0.f, 0.f);
+        if (i == u) x = make_float2(1.f, 0.f);
+        vr[a] = x;
+        const int j = 16 * a + tj;
+        float2 y = (j > u && j < D) ? cmul(col[j], sc) : make_float2(0.f, 0.f);
+        if (j == u) y = make_float2(1.f, 0.f);
+        vc[a] = y;
+    }
+    // keep the reflector for the Q accumulation: row u of the (consumed) global image
+    if (tid < D) {
+        float2 x = (tid > u) ? cmul(col[tid], sc) : make_float2(0.f, 0.f);
+        if (tid == u) x = make_float2(1.f, 0.f);
+        Mg[(int64_t)u * D + tid] = x;
+    }
+    if (tr == 0.f && tim == 0.f) return;   // H = I (uniform)
+
+    // p = tau * M v : partial over my columns, summed along the 16 fast lanes
+    float2 pr[NA];
+    float2 dotp = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int a = A0; a < NA; ++a) {
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int b = A0; b < NA; ++b) {
+            const float2 mm = m[a][b], vv = vc[b];
+            acc.x = fmaf(mm.x, vv.x, fmaf(-mm.y, vv.y, acc.x));
+            acc.y = fmaf(mm.x, vv.y, fmaf(mm.y, vv.x, acc.y));
+        }
+        acc.x = row16_sum(acc.x);
+        acc.y = row16_sum(acc.y);
+        const float2 p = cmul(tau, acc);
+        pr[a] = p;
+        if (tj == a) {   // one lane per row publishes p_i and its share of p^H v
+            sh.pbuf[par][16 * a + ti] = p;
+            dotp = cmacc(dotp, p, vr[a]);
+        }
+    }
+    dotp.x = wave_sum(dotp.x);
+    dotp.y = wave_sum(dotp.y);
+    if (lane == 0) sh.dotbuf[par][wave] = dotp;
+    __syncthreads();   // (B) p and the dot partials visible
+    float2 dot = sh.dotbuf[par][0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        dot.x += sh.dotbuf[par][q].x;
+        dot.y += sh.dotbuf[par][q].y;
+    }
+    float2 al = cmul(tau, dot);
+    al.x *= -0.5f;
+    al.y *= -0.5f;
+    float2 wr[NA], wc[NA];
+#pragma unroll
+    for (int a = A0; a < NA; ++a) {
+        const int i = 16 * a + ti, j = 16 * a + tj;
+        const float2 t1 = cmul(al, vr[a]);
+        wr[a] = (i >= u && i < D) ? make_float2(pr[a].x + t1.x, pr[a].y + t1.y) : make_float2(0.f, 0.f);
+        const float2 pj = sh.pbuf[par][j];
+        const float2 t2 = cmul(al, vc[a]);
+        wc[a] = (j >= u && j < D) ? make_float2(pj.x + t2.x, pj.y + t2.y) : make_float2(0.f, 0.f);
+    }
+    // M -= v w^H + w v^H on the active block
+#pragma unroll
+    for (int a = A0; a < NA; ++a)
+#pragma unroll
+        for (int b = A0; b < NA; ++b) {
+            const float2 t1 = cmulc(vr[a], wc[b]), t2 = cmulc(wr[a], vc[b]);
+            float2 mm = m[a][b];
+            mm.x -= t1.x + t2.x;
+            mm.y -= t1.y + t2.y;
+            if (a == b && ti == tj) mm.y = 0.f;
+            m[a][b] = mm;
+        }
+}
+
+// P <- P (I - conj(tau) v v^H) for the reflector with unit entry u, 16*A0 <= u < 16*(A0+1)
+template <int NA, int A0>
+__device__ __forceinline__ void q_step(float2 (&m)[NA][NA], const TrShared<NA> &sh, int u, int D,
+                                       const float2 *__restrict__ Mg) {
+    const int tj = threadIdx.x & 15;
+    const float2 tau = sh.taus[u];
+    if (tau.x == 0.f && tau.y == 0.f) return;
+    float2 vc[NA];
+#pragma unroll
+    for (int b = A0; b < NA; ++b) {
+        const int j = 16 * b + tj;
+        vc[b] = (j < D) ? Mg[(int64_t)u * D + j] : make_float2(0.f, 0.f);
+    }
+    const float2 ctau = make_float2(tau.x, -tau.y);
+#pragma unroll
+    for (int a = A0; a < NA; ++a) {
+        float2 y = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int b = A0; b < NA; ++b) {
+            const float2 pp = m[a][b], vv = vc[b];
+            y.x = fmaf(pp.x, vv.x, fmaf(-pp.y, vv.y, y.x));
+            y.y = fmaf(pp.x, vv.y, fmaf(pp.y, vv.x, y.y));
+        }
+        y.x = row16_sum(y.x);
+        y.y = row16_sum(y.y);
+        const float2 ty = cmul(ctau, y);
+#pragma unroll
+        for (int b = A0; b < NA; ++b) {
+            const float2 t = cmulc(ty, vc[b]);   // conj(tau) y conj(v_b)
+            m[a][b].x -= t.x;
+            m[a][b].y -= t.y;
+        }
+    }
+}
+
+template <int NA, int A0>
+struct TrPhases {
+    static __device__ __forceinline__ void forward(float2 (&m)[NA][NA], TrShared<NA> &sh, int D, float corner,
+                                                   const float2 *ag, float2 *Mg, float *dcol, float *ecol) {
+        const int hi = min(16 * (A0 + 1), D);
+        for (int u = 16 * A0; u < hi; ++u) tr_step<NA, A0>(m, sh, u, D, corner, ag, Mg, dcol, ecol);
+        if constexpr (A0 + 1 < NA) TrPhases<NA, A0 + 1>::forward(m, sh, D, corner, ag, Mg, dcol, ecol);
+    }
+    static __device__ __forceinline__ void backward(float2 (&m)[NA][NA], const TrShared<NA> &sh, int D,
+                                                    const float2 *Mg) {
+        if constexpr (A0 + 1 < NA) TrPhases<NA, A0 + 1>::backward(m, sh, D, Mg);
+        const int hi = min(16 * (A0 + 1), D);
+        for (int u = hi - 1; u >= 16 * A0; --u) q_step<NA, A0>(m, sh, u, D, Mg);
+    }
+};
+
+template <int NA>
+__global__ __launch_bounds__(TR_THREADS, 2) void tridiag_reg_kernel(int D, float2 *__restrict__ Mbuf,
+                                                                    float *__restrict__ QV,
+                                                                    float *__restrict__ dT,
+                                                                    float *__restrict__ eT) {
+    __shared__ TrShared<NA> sh;
+    const int tid = threadIdx.x;
+    const int tj = tid & 15, ti = tid >> 4;
+    const int64_t bm = blockIdx.x;
+    const int n = D + 1;
+    float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
+    const float2 *ag = Mg + (int64_t)D * D;
+    float *dcol = dT + bm * n;
+    float *ecol = eT + bm * n;
+
+    float2 m[NA][NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NA; ++b) {
+            const int i = 16 * a + ti, j = 16 * b + tj;
+            m[a][b] = (i < D && j < D) ? Mg[(int64_t)i * D + j] : make_float2(0.f, 0.f);
+        }
+    const float corner = ag[D].x;
+    __syncthreads();   // all loads done before Mg rows are overwritten with reflectors
+
+    // ---------------- tridiagonalisation: reflector u has its unit entry at index u ----------
+    TrPhases<NA, 0>::forward(m, sh, D, corner, ag, Mg, dcol, ecol);
+    // last diagonal entry d[D] = Re M[D-1][D-1]
+    {
+        const int k = D - 1, ka = k >> 4;
+        if (ti == (k & 15) && tj == (k & 15)) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+                if (a == ka) {
+                    dcol[D] = m[a][a].x;
+                    ecol[D] = 0.f;
+                }
+        }
+    }
+    __syncthreads();   // reflector rows in Mg and taus[] complete
+
+    // ---------------- explicit Q, accumulated as P = Q^H:  P <- P (I - conj(tau) v v^H) -------
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NA; ++b) m[a][b] = make_float2((a == b && ti == tj) ? 1.f : 0.f, 0.f);
+    TrPhases<NA, 0>::backward(m, sh, D, Mg);
+    // ---------------- QT[c][rho] = Q[rho][c] = conj(P[c][rho]) ---------------------------------
+    float *q = QV + bm * ((int64_t)n * 2 * D);
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NA; ++b) {
+            const int c = 16 * a + ti, rho = 16 * b + tj;
+            if (c < D && rho < D) {
+                q[(int64_t)c * 2 * D + rho] = m[a][b].x;
+                q[(int64_t)c * 2 * D + D + rho] = -m[a][b].y;
+            }
+        }
+}
+
+template <int NA>
+static int launch_tr(int D, int64_t nb, const Ws &ws, hipStream_t st) {
+    hipLaunchKernelGGL(tridiag_reg_kernel<NA>, dim3((unsigned)nb), dim3(TR_THREADS), 0, st, D, ws.Mbuf, ws.QV,
+                       ws.dT, ws.eT);
+    ADMM_HIP(hipGetLastError());
+    return ADMMNET_OK;
+}
+
+int launch_tridiag_reg(int D, int64_t nb, const Ws &ws, hipStream_t st) {
+    const int na = (D + 15) / 16;
+    switch (na) {
+        case 1: return launch_tr<1>(D, nb, ws, st);
+        case 2: return launch_tr<2>(D, nb, ws, st);
+        case 3: return launch_tr<3>(D, nb, ws, st);
+        case 4: return launch_tr<4>(D, nb, ws, st);
+        case 5: return launch_tr<5>(D, nb, ws, st);
+        case 6: return launch_tr<6>(D, nb, ws, st);
+        case 7: return launch_tr<7>(D, nb, ws, st);
+        case 8: return launch_tr<8>(D, nb, ws, st);
+        default:
+            set_error("tridiag_reg: D=%d unsupported", D);
+            return ADMMNET_E_ARG;
+    }
+}
+
+}  // namespace admmnet

@@ -88,7 +88,7 @@ int hm_tql(int n, float *d, float *e, float *z0, LogRec *log, int cap, int *nrec
     LogWriter lw{log, cap, 0, 0, 0};
     int ns = 0;
     // g_variant 0: textbook organisation (tql_lane); 1: the prefetching variant the device runs
-    int st = g_variant ? tql_lane_pf(n, D, E, Z, lw, 60, ns) : tql_lane(n, D, E, Z, lw, 60, ns);
+    int st = g_variant ? tql_lane_pf<5>(n, D, E, Z, lw, 60, ns) : tql_lane(n, D, E, Z, lw, 60, ns);
     *nrec = lw.pos;
     *nsweeps = ns;
     return st;
