@@ -2,6 +2,7 @@
 // weight packing, workspace carving and the per-layer launch sequence.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -65,6 +66,16 @@ static int check_cfg(const admmnet_cfg *cfg) {
     return ADMMNET_OK;
 }
 
+// Tridiagonal eigensolver: divide & conquer (default) or QL + rotation replay (ADMMNET_EIG=ql).
+bool use_dc() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("ADMMNET_EIG");
+        v = (e && !strcmp(e, "ql")) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 int64_t pick_chunk(const admmnet_cfg *cfg, int64_t B) {
     int64_t c = cfg->chunk > 0 ? cfg->chunk : 8192;
     if (c > B) c = B;
@@ -95,8 +106,16 @@ static void carve_chunk(Carver &c, int D, int64_t chunk, Ws *ws) {
     ws->eT = c.take<float>(groups * n * 64);
     ws->w = c.take<float>(chunk * n);
     ws->w0 = c.take<float>(chunk * n);
-    ws->log = c.take<LogRec>(chunk * ws->cap);
     ws->logn = c.take<int>(chunk * 2);
+    if (use_dc()) {
+        ws->Wdc = c.take<float>(chunk * 3 * n * n);
+        ws->VT = c.take<float>(chunk * n * 2 * D);
+        ws->log = nullptr;
+    } else {
+        ws->log = c.take<LogRec>(chunk * ws->cap);
+        ws->Wdc = nullptr;
+        ws->VT = ws->QV;   // the rotation replay works in place
+    }
 }
 
 int64_t eig_chunk_bytes(int D, int64_t chunk) {
@@ -134,9 +153,12 @@ int carve_workspace(const admmnet_cfg *cfg, int64_t B, void *base, int64_t bytes
 static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st) {
     int rc;
     if ((rc = launch_tridiag(D, nb, ws, st))) return rc;
+    if (ws.Wdc) {   // divide & conquer + V = Q W on the matrix cores
+        if ((rc = launch_dc(D + 1, nb, ws, status, st))) return rc;
+        return launch_vgemm(D, nb, ws, st);
+    }
     if ((rc = launch_tql(D + 1, nb, ws, status, st))) return rc;
-    if ((rc = launch_rotapply(D, nb, ws, st))) return rc;
-    return ADMMNET_OK;
+    return launch_rotapply(D, nb, ws, st);
 }
 
 }  // namespace admmnet

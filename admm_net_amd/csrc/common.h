@@ -94,6 +94,8 @@ struct Ws {
     float *QV;                // [chunk][n][2D] planar transposed: QT (D columns) then VT (n columns)
     float *dT, *eT;           // [chunk][n] tridiagonal (diagonal, off-diagonal)
     float *w, *w0;            // [chunk][n] eigenvalues, first row of W
+    float *Wdc;               // [chunk][3][n][n] divide & conquer: two WT ping-pong buffers + U (null: QL path)
+    float *VT;                // [chunk][n][2D] eigenvectors for the rebuild (= QV on the QL path)
     LogRec *log;              // [chunk][cap], 64-byte groups (eig_core.h)
     int *logn;                // [chunk][2]: records, status
     int64_t chunk;            // signals per chunk
@@ -120,6 +122,9 @@ int launch_tql(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st)
 // rotapply.hip
 int launch_rotapply(int D, int64_t nb, const Ws &ws, hipStream_t st);
 // rebuild.hip
+int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st);     // dc.hip
+int launch_vgemm(int D, int64_t nb, const Ws &ws, hipStream_t st);                       // dc.hip
+bool use_dc();                                                                          // api.hip
 int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h,
                    float2 *G, float *rn, float *w_out, const Ws &ws, hipStream_t st);
 int launch_vout(int n, int64_t nb, float2 *V, float *w, const Ws &ws, hipStream_t st);

@@ -1,0 +1,399 @@
+// dc.hip -- K2': divide & conquer eigensolver for the real symmetric tridiagonal matrices,
+// one 256-thread workgroup per matrix; K3': V = Q W on the matrix cores.
+//
+// Replaces the QL + rotation-replay pair (tql.hip / rotapply.hip) for the second half of
+// torch.linalg.eigh (/root/reference/admm_net.py:303): LAPACK sstedc semantics -- tear T into
+// leaves of 8, solve the leaves, then merge pairs level by level: sort, deflate (slaed2), solve
+// the secular equation per root (slaed4's job, here a bracketed Illinois iteration on the
+// pole-free transform), rebuild z by Loewner's formula (slaed3) and multiply the eigenvector
+// blocks (v_mfma_f32_32x32x2_f32).  Every phase except the O(n) deflation scan is parallel over
+// eigenvalues; clusters deflate instead of costing QL sweeps; the eigenvectors come out sorted.
+// The scalar pieces live in dc_core.h and are shared with tests/host_model/dc_model.cpp.
+//
+// Layouts: eigenvector blocks are kept transposed, WT[j][i] = W[i][j] (j = eigenvalue index), in
+// two ping-pong n x n global buffers per matrix (L2 resident); U of every merge goes to a third.
+#include "common.h"
+#include "dc_core.h"
+
+namespace admmnet {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int DC_THREADS = 256;
+constexpr int DC_LS = 8;          // leaf size (the last leaf absorbs the remainder)
+constexpr int DC_MAXLEAF = 33;    // n <= 8 * 33 + 7
+constexpr int DC_MAXLS = 2 * DC_LS;
+
+struct DcShared {
+    int bnd[2][DC_MAXLEAF + 2];
+    int kk[DC_MAXLEAF];      // non-deflated count per merge
+    int nrot[DC_MAXLEAF];
+    int fail;
+};
+
+__global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__restrict__ dT,
+                                                        const float *__restrict__ eT, float *__restrict__ Wbuf,
+                                                        float *__restrict__ wout, float *__restrict__ w0out,
+                                                        int *__restrict__ logn, int32_t *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ DcShared sh;
+    const int tid = threadIdx.x;
+    const int64_t bm = blockIdx.x;
+    const int NP = (n + 3) & ~3;
+    // LDS carve (floats / ints of length NP each)
+    float *lam = reinterpret_cast<float *>(smem);
+    float *e0 = lam + NP;
+    float *zv = e0 + NP;
+    float *ds = zv + NP;
+    float *zs = ds + NP;
+    float *dl = zs + NP;
+    float *zl = dl + NP;
+    float *tau = zl + NP;
+    float *zh = tau + NP;
+    float *vals = zh + NP;
+    float *lamn = vals + NP;
+    int *perm = reinterpret_cast<int *>(lamn + NP);
+    int *src = perm + NP;
+    int *org = src + NP;
+    int *rnk = org + NP;
+    DcRot *rot = reinterpret_cast<DcRot *>(rnk + NP);          // [NP]
+    float *leafZ = reinterpret_cast<float *>(rot + NP);         // [nleaf][DC_MAXLS * DC_MAXLS]
+    float *leafD = leafZ + (size_t)max(1, n / DC_LS) * DC_MAXLS * DC_MAXLS;   // [nleaf][2 * DC_MAXLS]
+
+    float *WA = Wbuf + bm * (int64_t)3 * n * n;
+    float *WB = WA + (int64_t)n * n;
+    float *U = WB + (int64_t)n * n;
+    const float *dg = dT + bm * n, *eg = eT + bm * n;
+
+    // ---- leaves
+    const int nleaf = max(1, n / DC_LS);
+    if (tid == 0) {
+        for (int b = 0; b < nleaf; ++b) sh.bnd[0][b] = b * DC_LS;
+        sh.bnd[0][nleaf] = n;
+        sh.fail = 0;
+    }
+    for (int i = tid; i < n; i += DC_THREADS) {
+        lam[i] = dg[i];
+        e0[i] = (i < n - 1) ? eg[i] : 0.f;
+    }
+    // both ping-pong buffers start at zero: every level writes only inside its diagonal blocks and
+    // the next level reads the (zero) off-diagonal blocks of the pair it merges
+    for (int64_t i = tid; i < (int64_t)2 * n * n; i += DC_THREADS) WA[i] = 0.f;
+    __syncthreads();
+    // tear: d[k-1] -= |e[k-1]|, d[k] -= |e[k-1]| at every leaf boundary k
+    for (int b = 1 + tid; b < nleaf; b += DC_THREADS) {
+        const int k = b * DC_LS;
+        const float r = fabsf(e0[k - 1]);
+        lam[k - 1] -= r;   // each boundary touches its own two entries (leaves have >= 8 rows)
+        lam[k] -= r;
+    }
+    __syncthreads();
+    if (tid < nleaf) {
+        const int a = sh.bnd[0][tid], s = sh.bnd[0][tid + 1] - a;
+        float *dd = leafD + (size_t)tid * 2 * DC_MAXLS, *ee = dd + DC_MAXLS;
+        float *Z = leafZ + (size_t)tid * DC_MAXLS * DC_MAXLS;
+        for (int i = 0; i < s; ++i) {
+            dd[i] = lam[a + i];
+            ee[i] = (i < s - 1) ? e0[a + i] : 0.f;
+        }
+        auto Zacc = [&](int i, int j) -> float & { return Z[i * DC_MAXLS + j]; };
+        if (leaf_ql(s, dd, ee, Zacc)) atomicAdd(&sh.fail, 1);
+        // ascending order by selection (s <= 15), then emit WT[j][i] = Z(i, idx_j)
+        for (int j = 0; j < s; ++j) {
+            int best = j;
+            for (int q = j + 1; q < s; ++q)
+                if (dd[q] < dd[best]) best = q;
+            if (best != j) {
+                const float t = dd[j];
+                dd[j] = dd[best];
+                dd[best] = t;
+                for (int i = 0; i < s; ++i) {
+                    const float u = Zacc(i, j);
+                    Zacc(i, j) = Zacc(i, best);
+                    Zacc(i, best) = u;
+                }
+            }
+            lam[a + j] = dd[j];
+            for (int i = 0; i < s; ++i) WA[(int64_t)(a + j) * n + a + i] = Zacc(i, j);
+        }
+    }
+    __syncthreads();
+
+    // ---- merge levels
+    int nblk = nleaf, cb = 0;
+    float *Ws = WA, *Wd = WB;
+    while (nblk > 1) {
+        const int nm = nblk >> 1;                 // merges at this level
+        const bool odd = nblk & 1;                // last block passes through
+        int ts = DC_THREADS;                      // team size: largest power of two with nm teams
+        while (ts * nm > DC_THREADS) ts >>= 1;
+        const int team = tid / ts, tl = tid - team * ts;
+        const bool act = team < nm;
+        const int *bn = sh.bnd[cb];
+        int a = 0, b = 0, c = 0;
+        if (act) {
+            a = bn[2 * team];
+            b = bn[2 * team + 1];
+            c = bn[2 * team + 2];
+        }
+        const int nn = c - a, n1 = b - a;
+        float rho = 0.f;
+        // P1: z, merged order
+        if (act) {
+            const float beta = e0[b - 1];
+            rho = 2.0f * fabsf(beta);
+            const float sg = (beta >= 0.f ? 1.f : -1.f) * 0.70710678118654752f;
+            for (int i = tl; i < nn; i += ts) {
+                const float z = (i < n1) ? Ws[(int64_t)(a + i) * n + (b - 1)] * 0.70710678118654752f
+                                         : Ws[(int64_t)(a + i) * n + b] * sg;
+                const float v = lam[a + i];
+                int r;
+                if (i < n1) {
+                    r = i;
+                    for (int q = n1; q < nn; ++q) r += (lam[a + q] < v);
+                } else {
+                    r = i - n1;
+                    for (int q = 0; q < n1; ++q) r += (lam[a + q] <= v);
+                }
+                perm[a + r] = i;
+                ds[a + r] = v;
+                zs[a + r] = z;
+            }
+        }
+        __syncthreads();
+        // P2: deflation scan (one thread per merge)
+        if (act && tl == 0) {
+            int k = 0, nr = 0;
+            deflate_scan(nn, rho, ds + a, zs + a, dl + a, zl + a, src + a, rot + a, k, nr);
+            sh.kk[team] = k;
+            sh.nrot[team] = nr;
+            for (int p = k; p < nn; ++p) vals[a + p] = dl[a + p];
+        }
+        __syncthreads();
+        const int k = act ? sh.kk[team] : 0;
+        // P3: deflation rotations on the source columns (thread-private rows i) + secular roots
+        if (act) {
+            const int nr = sh.nrot[team];
+            for (int r = 0; r < nr; ++r) {
+                const DcRot rr = rot[a + r];
+                float *x = Ws + (int64_t)(a + perm[a + rr.pa]) * n + a;
+                float *y = Ws + (int64_t)(a + perm[a + rr.pb]) * n + a;
+                for (int i = tl; i < nn; i += ts) {
+                    const float xi = x[i], yi = y[i];
+                    x[i] = rr.c * xi + rr.s * yi;
+                    y[i] = rr.c * yi - rr.s * xi;
+                }
+            }
+            for (int j = tl; j < k; j += ts) {
+                int o;
+                float t;
+                secular_root(k, j, rho, dl + a, zl + a, o, t);
+                org[a + j] = o;
+                tau[a + j] = t;
+                vals[a + j] = dl[a + o] + t;
+            }
+        }
+        __syncthreads();
+        // P4: Loewner z-hat, final (ascending, stable) positions
+        if (act) {
+            for (int i = tl; i < k; i += ts) zh[a + i] = lowner_zhat(k, i, dl + a, zl + a, org + a, tau + a);
+            for (int p = tl; p < nn; p += ts) {
+                const float v = vals[a + p];
+                int r = 0;
+                for (int q = 0; q < nn; ++q) {
+                    const float u = vals[a + q];
+                    r += (u < v) || (u == v && q < p);
+                }
+                rnk[a + p] = r;
+                lamn[a + r] = v;
+            }
+        }
+        __syncthreads();
+        // P5: normalised eigenvectors of the rank-one update, U[kk][j] (kk pole, j root)
+        if (act) {
+            for (int j = tl; j < k; j += ts) {
+                float nrm = 0.f;
+                for (int i = 0; i < k; ++i) {
+                    const float u = zh[a + i] / dc_delta(dl + a, org + a, tau + a, i, j);
+                    nrm = fmaf(u, u, nrm);
+                }
+                const float inv = 1.0f / sqrtf(nrm);
+                for (int i = 0; i < k; ++i) {
+                    const float u = zh[a + i] / dc_delta(dl + a, org + a, tau + a, i, j);
+                    U[(int64_t)(a + i) * n + a + j] = u * inv;
+                }
+            }
+        }
+        __syncthreads();
+        // P6: new blocks.  Deflated columns are copied, the others come from the GEMM
+        //     WTdst[rank(j)][i] = sum_kk U[kk][j] * WTsrc[col(src[kk])][i]   (MFMA, waves take tiles)
+        if (act) {
+            for (int p = k + (tl / 32); p < nn; p += max(1, ts / 32)) {   // 32 lanes per column copy
+                const float *xs = Ws + (int64_t)(a + perm[a + src[a + p]]) * n + a;
+                float *xd = Wd + (int64_t)(a + rnk[a + p]) * n + a;
+                for (int i = (ts >= 32 ? (tl & 31) : tl); i < nn; i += (ts >= 32 ? 32 : ts)) xd[i] = xs[i];
+            }
+        }
+        if (odd) {   // pass the unpaired block through
+            const int pa = bn[nblk - 1], pc = bn[nblk];
+            const int w = pc - pa;
+            for (int idx = tid; idx < w * w; idx += DC_THREADS) {
+                const int j = idx / w, i = idx - j * w;
+                Wd[(int64_t)(pa + j) * n + pa + i] = Ws[(int64_t)(pa + j) * n + pa + i];
+            }
+            for (int i = tid; i < w; i += DC_THREADS) lamn[pa + i] = lam[pa + i];
+        }
+        {
+            const int wave = tid >> 6, lane = tid & 63;
+            const int r = lane & 31, kh = lane >> 5;
+            int gbase = 0;   // tiles of all merges of the level are dealt round-robin to the 4 waves
+            for (int mm = 0; mm < nm; ++mm) {
+                const int ma = bn[2 * mm], mc = bn[2 * mm + 2];
+                const int mnn = mc - ma, mk = sh.kk[mm];
+                const int tm = (mk + 31) >> 5, tn = (mnn + 31) >> 5;
+                const int first = (wave - gbase) & 3;
+                gbase += tm * tn;
+                for (int t = first; t < tm * tn; t += DC_THREADS / 64) {
+                    const int j0 = (t / tn) * 32, i0 = (t % tn) * 32;
+                    const bool jv = (j0 + r) < mk, iv = (i0 + r) < mnn;
+                    f32x16 acc = {0};
+                    for (int k0 = 0; k0 < mk; k0 += 2) {
+                        const int kq = k0 + kh;
+                        const bool kv = kq < mk;
+                        const int kc = kv ? kq : 0;
+                        // A[j][kk] = U[kk][j]; B[kk][i] = WTsrc[col(src[kk])][i]
+                        float av = U[(int64_t)(ma + kc) * n + ma + (jv ? j0 + r : 0)];
+                        float bv = Ws[(int64_t)(ma + perm[ma + src[ma + kc]]) * n + ma + (iv ? i0 + r : 0)];
+                        av = (kv && jv) ? av : 0.f;
+                        bv = (kv && iv) ? bv : 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int j = j0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                        const int i = i0 + r;
+                        if (j < mk && i < mnn) Wd[(int64_t)(ma + rnk[ma + j]) * n + ma + i] = acc[q];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // P7: commit eigenvalues and block boundaries
+        for (int i = tid; i < n; i += DC_THREADS) lam[i] = lamn[i];
+        if (tid == 0) {
+            int o = 0;
+            for (int q = 0; q < nm; ++q) sh.bnd[cb ^ 1][o++] = bn[2 * q];
+            if (odd) sh.bnd[cb ^ 1][o++] = bn[nblk - 1];
+            sh.bnd[cb ^ 1][o] = n;
+        }
+        __syncthreads();
+        nblk = nm + (odd ? 1 : 0);
+        cb ^= 1;
+        float *tmp = Ws;
+        Ws = Wd;
+        Wd = tmp;
+    }
+    // ---- outputs: eigenvalues (ascending), first row of W, status, and W row-major (W[i][j], j =
+    //      eigenvalue) in the U region: the orientation the V = Q W product reads coalesced
+    for (int i = tid; i < n; i += DC_THREADS) {
+        wout[bm * n + i] = lam[i];
+        w0out[bm * n + i] = Ws[(int64_t)i * n];
+    }
+    {
+        float *tile = leafZ;   // 32 x 33 floats (the leaf scratch is dead by now)
+        const int tt = (n + 31) >> 5;
+        const int lx = tid & 31, ly = tid >> 5;   // 32 x 8 threads
+        for (int t = 0; t < tt * tt; ++t) {
+            const int j0 = (t / tt) * 32, i0 = (t % tt) * 32;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int jj = ly + 8 * q;
+                tile[jj * 33 + lx] = (j0 + jj < n && i0 + lx < n) ? Ws[(int64_t)(j0 + jj) * n + i0 + lx] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ii = ly + 8 * q;
+                if (i0 + ii < n && j0 + lx < n) U[(int64_t)(i0 + ii) * n + j0 + lx] = tile[lx * 33 + ii];
+            }
+        }
+    }
+    if (tid == 0) {
+        logn[bm * 2 + 0] = 0;
+        logn[bm * 2 + 1] = sh.fail ? 1 : 0;
+        if (sh.fail && status) atomicAdd(status, 1);
+    }
+}
+
+// K3': VT[c][rho] = sum_r W[1 + r][c] * QT[r][rho]   (V = diag(1, Q') W in the planar transposed layout)
+//   W: [n][n] row-major from dc_kernel (third buffer), QT: [D][2D] from the tridiagonalisation,
+//   VT: [n][2D].  One workgroup (4 waves) per matrix; the 32 x 32 output tiles are dealt round-robin
+//   to the waves; both operands are read straight from L2 in the MFMA lane layout (coalesced rows).
+__global__ __launch_bounds__(256) void vgemm_kernel(int D, const float *__restrict__ Wbuf,
+                                                    const float *__restrict__ QT, float *__restrict__ VT) {
+    const int n = D + 1;
+    const int64_t bm = blockIdx.x;
+    const float *Wr = Wbuf + bm * (int64_t)3 * n * n + (int64_t)2 * n * n;
+    const float *Q = QT + bm * ((int64_t)n * 2 * D);
+    float *V = VT + bm * ((int64_t)n * 2 * D);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, kh = lane >> 5;
+    const int tm = (n + 31) >> 5, tn = (2 * D + 31) >> 5;
+    for (int t = wave; t < tm * tn; t += 4) {
+        const int c0 = 32 * (t / tn), p0 = 32 * (t % tn);
+        const bool cv = (c0 + r) < n, pv = (p0 + r) < 2 * D;
+        const int co = cv ? c0 + r : 0, po = pv ? p0 + r : 0;
+        f32x16 acc = {0};
+#pragma unroll 8
+        for (int k0 = 0; k0 < D; k0 += 2) {
+            const int rr = k0 + kh;
+            const bool kv = rr < D;
+            const int rc = kv ? rr : 0;
+            float av = Wr[(int64_t)(1 + rc) * n + co];
+            float bv = Q[(int64_t)rc * 2 * D + po];
+            av = (kv && cv) ? av : 0.f;
+            bv = (kv && pv) ? bv : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = c0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+            if (c < n && pv) V[(int64_t)c * 2 * D + p0 + r] = acc[q];
+        }
+    }
+}
+
+size_t dc_lds_bytes(int n) {
+    const int NP = (n + 3) & ~3;
+    const size_t nleaf = (size_t)(n / DC_LS > 0 ? n / DC_LS : 1);
+    size_t leaf = nleaf * DC_MAXLS * DC_MAXLS + nleaf * 2 * DC_MAXLS;
+    if (leaf < 32 * 33) leaf = 32 * 33;   // the final transpose reuses the leaf scratch as a tile
+    return sizeof(float) * 11 * NP + sizeof(int) * 4 * NP + sizeof(DcRot) * NP + sizeof(float) * leaf;
+}
+
+int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st) {
+    ProfScope _prof(KC_TQL, st);
+    if (nb <= 0) return ADMMNET_OK;
+    if (n / DC_LS > DC_MAXLEAF) {
+        set_error("dc: n=%d unsupported", n);
+        return ADMMNET_E_ARG;
+    }
+    const size_t lds = dc_lds_bytes(n);
+    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dc_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(dc_kernel, dim3((unsigned)nb), dim3(DC_THREADS), lds, st, n, ws.dT, ws.eT, ws.Wdc, ws.w,
+                       ws.w0, ws.logn, status);
+    ADMM_HIP(hipGetLastError());
+    return ADMMNET_OK;
+}
+
+int launch_vgemm(int D, int64_t nb, const Ws &ws, hipStream_t st) {
+    ProfScope _prof(KC_ROTAPPLY, st);
+    if (nb <= 0) return ADMMNET_OK;
+    hipLaunchKernelGGL(vgemm_kernel, dim3((unsigned)nb), dim3(256), 0, st, D, ws.Wdc, ws.QV, ws.VT);
+    ADMM_HIP(hipGetLastError());
+    return ADMMNET_OK;
+}
+
+}  // namespace admmnet

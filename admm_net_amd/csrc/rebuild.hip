@@ -175,7 +175,7 @@ int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const 
     if (nb <= 0) return ADMMNET_OK;
     const int n = D + 1;
     const size_t lds = sizeof(float) * (2 * ((n + 4) & ~3) + 2 * D + 8);
-    hipLaunchKernelGGL(rebuild_kernel, dim3((unsigned)nb), dim3(RB_THREADS), lds, st, D, lw, ws.QV, ws.w,
+    hipLaunchKernelGGL(rebuild_kernel, dim3((unsigned)nb), dim3(RB_THREADS), lds, st, D, lw, ws.VT, ws.w,
                        ws.w0, phi, h, G, rn);
     ADMM_HIP(hipGetLastError());
     if (w_out) ADMM_HIP(hipMemcpyAsync(w_out, ws.w, sizeof(float) * nb * n, hipMemcpyDeviceToDevice, st));
@@ -184,7 +184,7 @@ int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const 
 
 int launch_vout(int n, int64_t nb, float2 *V, float *w, const Ws &ws, hipStream_t st) {
     if (nb <= 0) return ADMMNET_OK;
-    hipLaunchKernelGGL(vout_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, ws.QV, ws.w0, V);
+    hipLaunchKernelGGL(vout_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, ws.VT, ws.w0, V);
     ADMM_HIP(hipGetLastError());
     if (w) ADMM_HIP(hipMemcpyAsync(w, ws.w, sizeof(float) * nb * n, hipMemcpyDeviceToDevice, st));
     return ADMMNET_OK;

@@ -90,11 +90,16 @@ def main():
         sys.exit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    local = local % torch.cuda.device_count()     # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("ADMMNET_DIST_BACKEND", "nccl")   # nccl = RCCL on ROCm; gloo for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import admm_net_amd as A
     from admm_net_amd import _lib, ops, sharded, synth
