@@ -88,33 +88,36 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
         lam[k] -= r;
     }
     __syncthreads();
-    if (tid < nleaf) {
-        const int a = sh.bnd[0][tid], s = sh.bnd[0][tid + 1] - a;
-        float *dd = leafD + (size_t)tid * 2 * DC_MAXLS, *ee = dd + DC_MAXLS;
-        float *Z = leafZ + (size_t)tid * DC_MAXLS * DC_MAXLS;
-        for (int i = 0; i < s; ++i) {
-            dd[i] = lam[a + i];
-            ee[i] = (i < s - 1) ? e0[a + i] : 0.f;
-        }
-        auto Zacc = [&](int i, int j) -> float & { return Z[i * DC_MAXLS + j]; };
-        if (leaf_ql(s, dd, ee, Zacc)) atomicAdd(&sh.fail, 1);
-        // ascending order by selection (s <= 15), then emit WT[j][i] = Z(i, idx_j)
-        for (int j = 0; j < s; ++j) {
-            int best = j;
-            for (int q = j + 1; q < s; ++q)
-                if (dd[q] < dd[best]) best = q;
-            if (best != j) {
-                const float t = dd[j];
-                dd[j] = dd[best];
-                dd[best] = t;
-                for (int i = 0; i < s; ++i) {
+    {   // a team of lanes per leaf: shared scalar recurrence, the rows of Z split over the lanes
+        int lt = 16;   // <= 16 lanes: a team never straddles a wave (its lanes run in lock-step)
+        while (lt * nleaf > DC_THREADS) lt >>= 1;
+        const int leaf = tid / lt, k0 = tid - leaf * lt;
+        if (leaf < nleaf) {
+            const int a = sh.bnd[0][leaf], s = sh.bnd[0][leaf + 1] - a;
+            float *dd = leafD + (size_t)leaf * 2 * DC_MAXLS, *ee = dd + DC_MAXLS;
+            float *Z = leafZ + (size_t)leaf * DC_MAXLS * DC_MAXLS;
+            for (int i = 0; i < s; ++i) {   // identical values from every lane of the team
+                dd[i] = lam[a + i];
+                ee[i] = (i < s - 1) ? e0[a + i] : 0.f;
+            }
+            auto Zacc = [&](int i, int j) -> float & { return Z[i * DC_MAXLS + j]; };
+            if (leaf_ql(s, dd, ee, Zacc, k0, lt) && k0 == 0) atomicAdd(&sh.fail, 1);
+            // ascending order by selection (s <= 15), then emit WT[j][i] = Z(i, idx_j)
+            for (int j = 0; j < s; ++j) {
+                int best = j;
+                for (int q = j + 1; q < s; ++q)
+                    if (dd[q] < dd[best]) best = q;
+                const float dj = dd[j], db = dd[best];
+                dd[j] = db;
+                dd[best] = dj;
+                for (int i = k0; i < s; i += lt) {
                     const float u = Zacc(i, j);
                     Zacc(i, j) = Zacc(i, best);
                     Zacc(i, best) = u;
+                    WA[(int64_t)(a + j) * n + a + i] = Zacc(i, j);
                 }
+                if (k0 == 0) lam[a + j] = db;
             }
-            lam[a + j] = dd[j];
-            for (int i = 0; i < s; ++i) WA[(int64_t)(a + j) * n + a + i] = Zacc(i, j);
         }
     }
     __syncthreads();
@@ -213,13 +216,14 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
         if (act) {
             for (int j = tl; j < k; j += ts) {
                 float nrm = 0.f;
+                const float dorg = dl[a + org[a + j]], tj = tau[a + j];
                 for (int i = 0; i < k; ++i) {
-                    const float u = zh[a + i] / dc_delta(dl + a, org + a, tau + a, i, j);
+                    const float u = fdiv_fast(zh[a + i], (dl[a + i] - dorg) - tj);
                     nrm = fmaf(u, u, nrm);
                 }
                 const float inv = 1.0f / sqrtf(nrm);
                 for (int i = 0; i < k; ++i) {
-                    const float u = zh[a + i] / dc_delta(dl + a, org + a, tau + a, i, j);
+                    const float u = fdiv_fast(zh[a + i], (dl[a + i] - dorg) - tj);
                     U[(int64_t)(a + i) * n + a + j] = u * inv;
                 }
             }

@@ -16,13 +16,26 @@
 
 namespace admmnet {
 
+// a / b with one v_rcp_f32 (1 ulp) on the device; exact division on the host.  Used where the
+// quotient only feeds an iteratively refined quantity (secular function) or a vector that is
+// normalised afterwards.
+HD float fdiv_fast(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return a * __builtin_amdgcn_rcpf(b);
+#else
+    return a / b;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
-// Leaf solver: implicit QL with eigenvectors on a tiny tridiagonal (s <= 16), one thread.
+// Leaf solver: implicit QL with eigenvectors on a tiny tridiagonal (s <= 16).
 // d[s], e[s] (e[i] couples i, i+1; e[s-1] ignored); Z row-major [s][ldz] receives the eigenvectors
-// (columns).  Returns 0 / 1 (no convergence).
+// (columns).  A team of `kstep` lanes may share one leaf: every lane runs the (cheap) scalar
+// recurrence on the shared d / e -- all lanes write identical values -- and owns the rows
+// k0, k0 + kstep, ... of Z.  (k0, kstep) = (0, 1) is the single-thread form.  Returns 0 / 1.
 template <class FA, class ZA>
-HD int leaf_ql(int s, FA d, FA e, ZA Z) {
-    for (int i = 0; i < s; ++i)
+HD int leaf_ql(int s, FA d, FA e, ZA Z, int k0 = 0, int kstep = 1) {
+    for (int i = k0; i < s; i += kstep)
         for (int j = 0; j < s; ++j) Z(i, j) = (i == j) ? 1.f : 0.f;
     if (s > 0) e[s - 1] = 0.f;
     for (int l = 0; l < s; ++l) {
@@ -58,7 +71,7 @@ HD int leaf_ql(int s, FA d, FA e, ZA Z) {
                     p = sn * r;
                     d[i + 1] = g + p;
                     g = c * r - b;
-                    for (int k = 0; k < s; ++k) {
+                    for (int k = k0; k < s; k += kstep) {
                         f = Z(k, i + 1);
                         Z(k, i + 1) = sn * Z(k, i) + c * f;
                         Z(k, i) = c * Z(k, i) - sn * f;
@@ -180,7 +193,7 @@ HD void secular_root(int k, int j, float rho, FA d, FA z, int &org_out, float &t
         const float dorg = d[org];
         for (int i = 0; i < k; ++i) {
             const float del = (d[i] - dorg) - t;
-            acc += z[i] * z[i] / del;
+            acc = fmaf(z[i] * z[i], fdiv_fast(1.0f, del), acc);
         }
         return 1.0f + rho * acc;
     };
