@@ -117,6 +117,7 @@ int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const flo
 // tridiag.hip
 int launch_tridiag(int D, int64_t nb, const Ws &ws, hipStream_t st);
 int launch_tridiag_reg(int D, int64_t nb, const Ws &ws, hipStream_t st);   // tridiag_reg.hip, D <= 128
+int launch_tridiag_big(int D, int64_t nb, const Ws &ws, hipStream_t st);   // tridiag_big.hip, 128 < D <= 256
 // tql.hip
 int launch_tql(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st);
 // rotapply.hip

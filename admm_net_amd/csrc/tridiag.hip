@@ -262,6 +262,7 @@ int launch_tridiag(int D, int64_t nb, const Ws &ws, hipStream_t st) {
         use_lds = (e && !strcmp(e, "lds")) ? 1 : 0;
     }
     if (D <= 128 && !use_lds) return launch_tridiag_reg(D, nb, ws, st);
+    if (D <= 256 && !use_lds) return launch_tridiag_big(D, nb, ws, st);
     const bool ldsm = td_lds_bytes(D, true) <= 160 * 1024;
     const size_t lds = td_lds_bytes(D, ldsm);
     if (ldsm) {

@@ -1,0 +1,341 @@
+// tridiag_big.hip -- K1 for 128 < D <= 256 (BASELINE cfg 3/4/5: D = 256, n = 257).
+//
+// A 256 x 256 complex matrix is 512 KB -- exactly the whole VGPR file of a CU -- so the
+// register-resident scheme of tridiag_reg.hip is applied to the HERMITIAN HALF: a 1024-thread
+// workgroup (32 x 32 grid, 2D-cyclic with period 32) keeps the block-lower triangle
+// (diagonal blocks in full): 36 complex block slots per thread at NA = 8.  The 128-VGPR budget of
+// a 1024-thread workgroup cannot hold them all (344 spills), so the diagonal and first
+// sub-diagonal block slots (15) live in LDS -- 120 KB, lane-contiguous, conflict free -- and the
+// other 21 in VGPRs.
+//   p = M v needs two reductions now: the row part along tj (the 32 fast lanes, DPP) and the
+//   mirrored part along ti (in-wave swap + one 32 KB LDS pass);  3 barriers per reflector.
+// The explicit Q (not Hermitian: 512 KB) is formed by a second kernel, ungtr_big_kernel, as
+// P = Q^H with its ROWS split over two workgroups (rows of P are independent under
+// P <- P H^H), barrier free.  Same mathematics as tridiag_reg.hip (LAPACK chetd2 + cung2l,
+// first half of torch.linalg.eigh at /root/reference/admm_net.py:303).
+#include "common.h"
+
+namespace admmnet {
+
+constexpr int TB_THREADS = 1024;
+
+__device__ __forceinline__ float row32_sum(float x) {   // all-reduce over the 32 lanes of a half wave
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xF, 0xF, false));
+    x += __shfl_xor(x, 16, 64);
+    return x;
+}
+
+template <int NA>
+struct TbShared {
+    float2 colbuf[2][32 * NA];
+    float2 prow[32 * NA];
+    float2 pfull[32 * NA];
+    float2 cpart[16][32 * (NA - 1)];
+    float2 dotbuf[16];
+};
+
+// Block (a, b), a >= b: the diagonal (a == b) and first sub-diagonal (a == b + 1) block slots live
+// in LDS (lds slot a, resp. NA + b), the rest in registers.
+constexpr __host__ __device__ int tb_slot(int a, int b) { return (a - 1) * (a - 2) / 2 + b; }   // a >= b + 2
+constexpr int tb_nslot(int na) { return (na - 1) * (na - 2) / 2 > 0 ? (na - 1) * (na - 2) / 2 : 1; }
+#define TB_LDS(a, b) dg[((a) == (b) ? (a) : NA + (b)) * TB_THREADS + threadIdx.x]
+#define TB_GET(a, b) ((a) - (b) <= 1 ? TB_LDS(a, b) : m[tb_slot((a), (b))])
+#define TB_SET(a, b, val)                         \
+    do {                                          \
+        if ((a) - (b) <= 1) TB_LDS(a, b) = (val); \
+        else m[tb_slot((a), (b))] = (val);        \
+    } while (0)
+
+template <int NA, int A0>
+__device__ __forceinline__ void tb_step(float2 (&m)[tb_nslot(NA)], float2 *__restrict__ dg, TbShared<NA> &sh,
+                                        int u, int D, float corner, float2 *__restrict__ Mg, float *__restrict__ dcol,
+                                        float *__restrict__ ecol) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tj = tid & 31, ti = tid >> 5;
+    const int par = u & 1;
+    if (u == 0) {
+        for (int i = tid; i < 32 * NA; i += TB_THREADS) sh.colbuf[0][i] = (i < D) ? Mg[(int64_t)D * D + i] : make_float2(0.f, 0.f);
+    } else {
+        const int k = u - 1;
+        if (tj == (k & 31)) {
+            if ((k >> 5) == A0) {
+#pragma unroll
+                for (int a = A0; a < NA; ++a) sh.colbuf[par][32 * a + ti] = TB_GET(a, A0);
+            } else {
+                constexpr int B = A0 > 0 ? A0 - 1 : 0;
+#pragma unroll
+                for (int a = B; a < NA; ++a) sh.colbuf[par][32 * a + ti] = TB_GET(a, B);
+            }
+        }
+    }
+    __syncthreads();   // (A)
+    const float2 *col = sh.colbuf[par];
+    float pn = 0.f;
+    for (int i = u + 1 + lane; i < D; i += 64) {
+        const float2 x = col[i];
+        pn += x.x * x.x + x.y * x.y;
+    }
+    const float xn2 = wave_sum(pn);
+    const float2 alpha = col[u];
+    float beta, tr, tim, sr, si;
+    householder_c(alpha.x, alpha.y, xn2, beta, tr, tim, sr, si);
+    const float2 tau = make_float2(tr, tim), sc = make_float2(sr, si);
+    auto vat = [&](int i) -> float2 {   // component i of the reflector (zero above the unit entry / beyond D)
+        float2 x = (i > u && i < D) ? cmul(col[i], sc) : make_float2(0.f, 0.f);
+        if (i == u) x = make_float2(1.f, 0.f);
+        return x;
+    };
+    if (tid == 0) {
+        ecol[u] = beta;
+        dcol[u] = (u == 0) ? corner : col[u - 1].x;
+    }
+    if (tid < D) Mg[(int64_t)u * D + tid] = vat(tid);          // reflector row u for the Q kernel
+    if (tid == 0) Mg[(int64_t)D * D + u] = tau;                 // taus live in the consumed arrow slot
+    if (tr == 0.f && tim == 0.f) return;                        // H = I (uniform)
+
+    // ---- p = M v with the Hermitian half, in two register-lean passes:
+    //      row part  sum_{j <= blk(i)} M_ij v_j  (reduce over tj, the 32 fast lanes), then the
+    //      mirrored part  sum_{i > blk(j)} conj(M_ij) v_i  (reduce over ti: in-wave swap + LDS)
+    {
+        float2 vc[NA];
+#pragma unroll
+        for (int b = A0; b < NA; ++b) vc[b] = vat(32 * b + tj);
+#pragma unroll
+        for (int a = A0; a < NA; ++a) {
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int b = A0; b <= a; ++b) {
+                const float2 x = TB_GET(a, b);
+                acc.x = fmaf(x.x, vc[b].x, fmaf(-x.y, vc[b].y, acc.x));
+                acc.y = fmaf(x.x, vc[b].y, fmaf(x.y, vc[b].x, acc.y));
+            }
+            acc.x = row32_sum(acc.x);
+            acc.y = row32_sum(acc.y);
+            if (tj == a) sh.prow[32 * a + ti] = acc;
+            __builtin_amdgcn_sched_barrier(0);   // keep the block-row loads inside their iteration (VGPR budget)
+        }
+    }
+    {
+        float2 vr[NA];
+#pragma unroll
+        for (int a = A0; a < NA; ++a) vr[a] = vat(32 * a + ti);
+#pragma unroll
+        for (int b = A0; b < NA - 1; ++b) {
+            float2 t = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int a = b + 1; a < NA; ++a) t = cmacc(t, TB_GET(a, b), vr[a]);   // conj(M_ij) v_i -> row j
+            t.x += __shfl_xor(t.x, 32, 64);
+            t.y += __shfl_xor(t.y, 32, 64);
+            if (lane < 32) sh.cpart[wave][32 * b + tj] = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();   // (B)
+    if (tid < 256) {
+        float2 dotp = make_float2(0.f, 0.f);
+        if (tid < 32 * NA && tid >= 32 * A0) {
+            float2 s = sh.prow[tid];
+            if ((tid >> 5) < NA - 1) {
+#pragma unroll
+                for (int w = 0; w < 16; ++w) {
+                    const float2 t = sh.cpart[w][tid];
+                    s.x += t.x;
+                    s.y += t.y;
+                }
+            }
+            const float2 p = cmul(tau, s);
+            sh.pfull[tid] = p;
+            dotp = cmacc(dotp, p, vat(tid));
+        }
+        dotp.x = wave_sum(dotp.x);
+        dotp.y = wave_sum(dotp.y);
+        if (lane == 0) sh.dotbuf[wave] = dotp;
+    }
+    __syncthreads();   // (C)
+    float2 dot = sh.dotbuf[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        dot.x += sh.dotbuf[q].x;
+        dot.y += sh.dotbuf[q].y;
+    }
+    float2 al = cmul(tau, dot);
+    al.x *= -0.5f;
+    al.y *= -0.5f;
+    auto wat = [&](int i, float2 v) -> float2 {
+        if (!(i >= u && i < D)) return make_float2(0.f, 0.f);
+        const float2 p = sh.pfull[i], t = cmul(al, v);
+        return make_float2(p.x + t.x, p.y + t.y);
+    };
+    float2 vc[NA], wc[NA];
+#pragma unroll
+    for (int b = A0; b < NA; ++b) {
+        vc[b] = vat(32 * b + tj);
+        wc[b] = wat(32 * b + tj, vc[b]);
+    }
+#pragma unroll
+    for (int a = A0; a < NA; ++a) {
+        const float2 vra = vat(32 * a + ti);
+        const float2 wra = wat(32 * a + ti, vra);
+#pragma unroll
+        for (int b = A0; b <= a; ++b) {
+            const float2 t1 = cmulc(vra, wc[b]), t2 = cmulc(wra, vc[b]);
+            float2 x = TB_GET(a, b);
+            x.x -= t1.x + t2.x;
+            x.y -= t1.y + t2.y;
+            if (a == b && ti == tj) x.y = 0.f;
+            TB_SET(a, b, x);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NA, int A0>
+struct TbPhases {
+    static __device__ __forceinline__ void run(float2 (&m)[tb_nslot(NA)], float2 *dg, TbShared<NA> &sh, int D,
+                                               float corner, float2 *Mg, float *dcol, float *ecol) {
+        const int hi = min(32 * (A0 + 1), D);
+        for (int u = 32 * A0; u < hi; ++u) tb_step<NA, A0>(m, dg, sh, u, D, corner, Mg, dcol, ecol);
+        if constexpr (A0 + 1 < NA) TbPhases<NA, A0 + 1>::run(m, dg, sh, D, corner, Mg, dcol, ecol);
+    }
+};
+
+template <int NA>
+__global__ __launch_bounds__(TB_THREADS) void tridiag_big_kernel(int D, float2 *__restrict__ Mbuf,
+                                                                 float *__restrict__ dT, float *__restrict__ eT) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    TbShared<NA> &sh = *reinterpret_cast<TbShared<NA> *>(smem);
+    float2 *dg = reinterpret_cast<float2 *>(smem + sizeof(TbShared<NA>));   // [2 NA - 1][1024] LDS block slots
+    const int tid = threadIdx.x;
+    const int tj = tid & 31, ti = tid >> 5;
+    const int64_t bm = blockIdx.x;
+    const int n = D + 1;
+    float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
+    float *dcol = dT + bm * n, *ecol = eT + bm * n;
+    float2 m[tb_nslot(NA)];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            const int i = 32 * a + ti, j = 32 * b + tj;
+            const float2 x = (i < D && j < D) ? Mg[(int64_t)i * D + j] : make_float2(0.f, 0.f);
+            TB_SET(a, b, x);
+        }
+    const float corner = Mg[(int64_t)D * D + D].x;
+    // cpart rows of the last block are never written: keep them zero-free by construction (guarded reads)
+    __syncthreads();
+    TbPhases<NA, 0>::run(m, dg, sh, D, corner, Mg, dcol, ecol);
+    {
+        const int k = D - 1, ka = k >> 5;
+        if (ti == (k & 31) && tj == (k & 31)) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+                if (a == ka) {
+                    dcol[D] = dg[a * TB_THREADS + tid].x;
+                    ecol[D] = 0.f;
+                }
+        }
+    }
+}
+
+// P = Q^H, rows [128 g, 128 g + 128) handled by workgroup g:  P <- P (I - conj(tau_u) v_u v_u^H), u = D-1 .. 0.
+template <int NB, int B0>
+__device__ __forceinline__ void ub_step(float2 (&p)[4][NB], int u, int D, const float2 *__restrict__ Mg) {
+    const int tj = threadIdx.x & 31;
+    const float2 tau = Mg[(int64_t)D * D + u];
+    if (tau.x == 0.f && tau.y == 0.f) return;
+    float2 vc[NB];
+#pragma unroll
+    for (int b = B0; b < NB; ++b) {
+        const int j = 32 * b + tj;
+        vc[b] = (j < D) ? Mg[(int64_t)u * D + j] : make_float2(0.f, 0.f);
+    }
+    const float2 ctau = make_float2(tau.x, -tau.y);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float2 y = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int b = B0; b < NB; ++b) {
+            const float2 pp = p[a][b], vv = vc[b];
+            y.x = fmaf(pp.x, vv.x, fmaf(-pp.y, vv.y, y.x));
+            y.y = fmaf(pp.x, vv.y, fmaf(pp.y, vv.x, y.y));
+        }
+        y.x = row32_sum(y.x);
+        y.y = row32_sum(y.y);
+        const float2 ty = cmul(ctau, y);
+#pragma unroll
+        for (int b = B0; b < NB; ++b) {
+            const float2 t = cmulc(ty, vc[b]);
+            p[a][b].x -= t.x;
+            p[a][b].y -= t.y;
+        }
+    }
+}
+
+template <int NB, int B0>
+struct UbPhases {
+    static __device__ __forceinline__ void run(float2 (&p)[4][NB], int D, const float2 *Mg) {
+        if constexpr (B0 + 1 < NB) UbPhases<NB, B0 + 1>::run(p, D, Mg);
+        const int hi = min(32 * (B0 + 1), D);
+        for (int u = hi - 1; u >= 32 * B0; --u) ub_step<NB, B0>(p, u, D, Mg);
+    }
+};
+
+template <int NB>
+__global__ __launch_bounds__(TB_THREADS) void ungtr_big_kernel(int D, const float2 *__restrict__ Mbuf,
+                                                               float *__restrict__ QV) {
+    const int tid = threadIdx.x;
+    const int tj = tid & 31, ti = tid >> 5;
+    const int64_t bm = blockIdx.x;
+    const int g = blockIdx.y;
+    const int n = D + 1;
+    const float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
+    float2 p[4][NB];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) p[a][b] = make_float2((128 * g + 32 * a + ti == 32 * b + tj) ? 1.f : 0.f, 0.f);
+    UbPhases<NB, 0>::run(p, D, Mg);
+    float *q = QV + bm * ((int64_t)n * 2 * D);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int c = 128 * g + 32 * a + ti, rho = 32 * b + tj;
+            if (c < D && rho < D) {
+                q[(int64_t)c * 2 * D + rho] = p[a][b].x;
+                q[(int64_t)c * 2 * D + D + rho] = -p[a][b].y;
+            }
+        }
+}
+
+template <int NA>
+static int launch_tb(int D, int64_t nb, const Ws &ws, hipStream_t st) {
+    const size_t lds = sizeof(TbShared<NA>) + sizeof(float2) * (2 * NA - 1) * TB_THREADS;
+    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_big_kernel<NA>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(tridiag_big_kernel<NA>, dim3((unsigned)nb), dim3(TB_THREADS), lds, st, D, ws.Mbuf, ws.dT,
+                       ws.eT);
+    ADMM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ungtr_big_kernel<NA>, dim3((unsigned)nb, (unsigned)((D + 127) / 128)), dim3(TB_THREADS), 0, st,
+                       D, ws.Mbuf, ws.QV);
+    ADMM_HIP(hipGetLastError());
+    return ADMMNET_OK;
+}
+
+int launch_tridiag_big(int D, int64_t nb, const Ws &ws, hipStream_t st) {
+    const int na = (D + 31) / 32;
+    switch (na) {
+        case 5: return launch_tb<5>(D, nb, ws, st);
+        case 6: return launch_tb<6>(D, nb, ws, st);
+        case 7: return launch_tb<7>(D, nb, ws, st);
+        case 8: return launch_tb<8>(D, nb, ws, st);
+        default:
+            set_error("tridiag_big: D=%d unsupported (129..256)", D);
+            return ADMMNET_E_ARG;
+    }
+}
+
+}  // namespace admmnet

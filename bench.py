@@ -36,7 +36,9 @@ WORKLOADS = {
     "cfg3": (16, 16, 16, 65536, 32, 32),
     "ref": (10, 10, 10, 4096, 32, 16),
 }
-KERNELS = ["prep", "tridiag", "tql", "rotapply", "rebuild", "zstep", "head", "spectrum"]
+# kernel classes of admmnet_profile_read (include/admmnet.h): "trideig" = tridiagonal eigensolver
+# (divide & conquer, or QL with ADMMNET_EIG=ql), "backtransform" = V = Q W (MFMA GEMM, or rotation replay)
+KERNELS = ["prep", "tridiag", "trideig", "backtransform", "rebuild", "zstep", "head", "spectrum"]
 
 
 def flops_per_signal(K, n, D, natoms):
@@ -46,7 +48,7 @@ def flops_per_signal(K, n, D, natoms):
 
 def kernel_flops_per_matrix(n):
     """Split of the canonical 24 n^3 per matrix over our kernels ('Kernels')."""
-    return {"tridiag": 16.0 / 3.0 * n ** 3, "tql": 8.0 / 3.0 * n ** 3, "rotapply": 8.0 * n ** 3,
+    return {"tridiag": 16.0 / 3.0 * n ** 3, "trideig": 8.0 / 3.0 * n ** 3, "backtransform": 8.0 * n ** 3,
             "rebuild": 8.0 * n ** 3}
 
 
@@ -162,7 +164,7 @@ def main():
         value = signals / dt
         F = flops_per_signal(K, n, D, natoms)
         per = {KERNELS[i]: (ms[i], cnt[i]) for i in range(8)}
-        dom = max(("tridiag", "tql", "rotapply", "rebuild"), key=lambda k_: per[k_][0])
+        dom = max(("tridiag", "trideig", "backtransform", "rebuild"), key=lambda k_: per[k_][0])
         kf = kernel_flops_per_matrix(n)[dom]
         chunk = min(B, 8192)
         launches = max(per[dom][1], 1)

@@ -166,8 +166,9 @@ int admmnet_spectrum_f64(const void *phi, int64_t B, int32_t xbase, int32_t ybas
  * When enabled, every kernel launcher brackets its launch with HIP events on the
  * caller's stream.  admmnet_profile_read synchronises those events, returns the
  * summed milliseconds and launch counts per kernel class and clears the buffer.
- * Classes: 0 prep, 1 tridiag, 2 tql, 3 rotapply, 4 rebuild, 5 zstep, 6 head,
- * 7 spectrum (ADMMNET_KERNEL_CLASSES entries).  Not thread safe; off by default. */
+ * Classes: 0 prep, 1 tridiag, 2 tridiagonal eigensolver, 3 back-transform (V = Q W),
+ * 4 rebuild, 5 zstep, 6 head, 7 spectrum (ADMMNET_KERNEL_CLASSES entries).
+ * Not thread safe; off by default. */
 #define ADMMNET_KERNEL_CLASSES 8
 int admmnet_profile_enable(int32_t on);
 int admmnet_profile_read(double *ms_total, int64_t *launches, int32_t nclasses);
