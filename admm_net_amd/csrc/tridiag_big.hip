@@ -28,6 +28,20 @@ __device__ __forceinline__ float row32_sum(float x) {   // all-reduce over the 3
     return x;
 }
 
+typedef float v2 __attribute__((ext_vector_type(2)));   // packed complex arithmetic, see tridiag_reg.hip
+__device__ __forceinline__ v2 b_tov2(float2 a) { return v2{a.x, a.y}; }
+__device__ __forceinline__ float2 b_tof2(v2 a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ v2 b_rot(v2 v) { return v2{-v.y, v.x}; }
+__device__ __forceinline__ v2 b_rotc(v2 v) { return v2{v.y, -v.x}; }
+__device__ __forceinline__ v2 b_cmac(v2 acc, v2 m, v2 v, v2 vj) {   // acc + m v, vj = rot(v)
+    acc = __builtin_elementwise_fma(m.xx, v, acc);
+    return __builtin_elementwise_fma(m.yy, vj, acc);
+}
+__device__ __forceinline__ v2 b_cmacc(v2 acc, v2 a, v2 aj, v2 b) {   // acc + a conj(b), aj = rotc(a)
+    acc = __builtin_elementwise_fma(b.xx, a, acc);
+    return __builtin_elementwise_fma(b.yy, aj, acc);
+}
+
 template <int NA>
 struct TbShared {
     float2 colbuf[2][32 * NA];
@@ -100,36 +114,36 @@ __device__ __forceinline__ void tb_step(float2 (&m)[tb_nslot(NA)], float2 *__res
     //      row part  sum_{j <= blk(i)} M_ij v_j  (reduce over tj, the 32 fast lanes), then the
     //      mirrored part  sum_{i > blk(j)} conj(M_ij) v_i  (reduce over ti: in-wave swap + LDS)
     {
-        float2 vc[NA];
+        v2 vc[NA];
 #pragma unroll
-        for (int b = A0; b < NA; ++b) vc[b] = vat(32 * b + tj);
+        for (int b = A0; b < NA; ++b) vc[b] = b_tov2(vat(32 * b + tj));
 #pragma unroll
         for (int a = A0; a < NA; ++a) {
-            float2 acc = make_float2(0.f, 0.f);
+            v2 acc = {0.f, 0.f};
 #pragma unroll
-            for (int b = A0; b <= a; ++b) {
-                const float2 x = TB_GET(a, b);
-                acc.x = fmaf(x.x, vc[b].x, fmaf(-x.y, vc[b].y, acc.x));
-                acc.y = fmaf(x.x, vc[b].y, fmaf(x.y, vc[b].x, acc.y));
-            }
+            for (int b = A0; b <= a; ++b) acc = b_cmac(acc, b_tov2(TB_GET(a, b)), vc[b], b_rot(vc[b]));
             acc.x = row32_sum(acc.x);
             acc.y = row32_sum(acc.y);
-            if (tj == a) sh.prow[32 * a + ti] = acc;
+            if (tj == a) sh.prow[32 * a + ti] = b_tof2(acc);
             __builtin_amdgcn_sched_barrier(0);   // keep the block-row loads inside their iteration (VGPR budget)
         }
     }
     {
-        float2 vr[NA];
+        v2 vr[NA];
 #pragma unroll
-        for (int a = A0; a < NA; ++a) vr[a] = vat(32 * a + ti);
+        for (int a = A0; a < NA; ++a) vr[a] = b_tov2(vat(32 * a + ti));
 #pragma unroll
         for (int b = A0; b < NA - 1; ++b) {
-            float2 t = make_float2(0.f, 0.f);
+            v2 t = {0.f, 0.f};
 #pragma unroll
-            for (int a = b + 1; a < NA; ++a) t = cmacc(t, TB_GET(a, b), vr[a]);   // conj(M_ij) v_i -> row j
+            for (int a = b + 1; a < NA; ++a) {   // conj(M_ij) v_i = x.x (v.x, v.y) + x.y (v.y, -v.x) -> row j
+                const v2 x = b_tov2(TB_GET(a, b));
+                t = __builtin_elementwise_fma(x.xx, vr[a], t);
+                t = __builtin_elementwise_fma(x.yy, b_rotc(vr[a]), t);
+            }
             t.x += __shfl_xor(t.x, 32, 64);
             t.y += __shfl_xor(t.y, 32, 64);
-            if (lane < 32) sh.cpart[wave][32 * b + tj] = t;
+            if (lane < 32) sh.cpart[wave][32 * b + tj] = b_tof2(t);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -169,24 +183,26 @@ __device__ __forceinline__ void tb_step(float2 (&m)[tb_nslot(NA)], float2 *__res
         const float2 p = sh.pfull[i], t = cmul(al, v);
         return make_float2(p.x + t.x, p.y + t.y);
     };
-    float2 vc[NA], wc[NA];
+    v2 vc[NA], wc[NA];
 #pragma unroll
     for (int b = A0; b < NA; ++b) {
-        vc[b] = vat(32 * b + tj);
-        wc[b] = wat(32 * b + tj, vc[b]);
+        const float2 v = vat(32 * b + tj);
+        vc[b] = b_tov2(v);
+        wc[b] = b_tov2(wat(32 * b + tj, v));
     }
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
-        const float2 vra = vat(32 * a + ti);
-        const float2 wra = wat(32 * a + ti, vra);
+        const float2 vf = vat(32 * a + ti);
+        const float2 wf = wat(32 * a + ti, vf);
+        const v2 vra = v2{-vf.x, -vf.y}, wra = v2{-wf.x, -wf.y};   // x += (-v_i) conj(w_j) + (-w_i) conj(v_j)
+        const v2 vraj = b_rotc(vra), wraj = b_rotc(wra);
 #pragma unroll
         for (int b = A0; b <= a; ++b) {
-            const float2 t1 = cmulc(vra, wc[b]), t2 = cmulc(wra, vc[b]);
-            float2 x = TB_GET(a, b);
-            x.x -= t1.x + t2.x;
-            x.y -= t1.y + t2.y;
+            v2 x = b_tov2(TB_GET(a, b));
+            x = b_cmacc(x, vra, vraj, wc[b]);
+            x = b_cmacc(x, wra, wraj, vc[b]);
             if (a == b && ti == tj) x.y = 0.f;
-            TB_SET(a, b, x);
+            TB_SET(a, b, b_tof2(x));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -246,31 +262,25 @@ __device__ __forceinline__ void ub_step(float2 (&p)[4][NB], int u, int D, const 
     const int tj = threadIdx.x & 31;
     const float2 tau = Mg[(int64_t)D * D + u];
     if (tau.x == 0.f && tau.y == 0.f) return;
-    float2 vc[NB];
+    v2 vc[NB], vj[NB];
 #pragma unroll
     for (int b = B0; b < NB; ++b) {
         const int j = 32 * b + tj;
-        vc[b] = (j < D) ? Mg[(int64_t)u * D + j] : make_float2(0.f, 0.f);
+        vc[b] = (j < D) ? b_tov2(Mg[(int64_t)u * D + j]) : v2{0.f, 0.f};
+        vj[b] = b_rot(vc[b]);
     }
     const float2 ctau = make_float2(tau.x, -tau.y);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        float2 y = make_float2(0.f, 0.f);
+        v2 y = {0.f, 0.f};
 #pragma unroll
-        for (int b = B0; b < NB; ++b) {
-            const float2 pp = p[a][b], vv = vc[b];
-            y.x = fmaf(pp.x, vv.x, fmaf(-pp.y, vv.y, y.x));
-            y.y = fmaf(pp.x, vv.y, fmaf(pp.y, vv.x, y.y));
-        }
+        for (int b = B0; b < NB; ++b) y = b_cmac(y, b_tov2(p[a][b]), vc[b], vj[b]);
         y.x = row32_sum(y.x);
         y.y = row32_sum(y.y);
-        const float2 ty = cmul(ctau, y);
+        const float2 ty = cmul(ctau, b_tof2(y));
+        const v2 nty = v2{-ty.x, -ty.y}, ntyj = b_rotc(nty);
 #pragma unroll
-        for (int b = B0; b < NB; ++b) {
-            const float2 t = cmulc(ty, vc[b]);
-            p[a][b].x -= t.x;
-            p[a][b].y -= t.y;
-        }
+        for (int b = B0; b < NB; ++b) p[a][b] = b_tof2(b_cmacc(b_tov2(p[a][b]), nty, ntyj, vc[b]));
     }
 }
 

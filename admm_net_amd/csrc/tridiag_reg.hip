@@ -28,6 +28,26 @@ __device__ __forceinline__ float row16_sum(float x) {
 }
 
 // Shared state of one workgroup's LDS vectors.
+// Complex arithmetic on (re, im) register pairs written so that hipcc emits ONE v_pk_fma_f32 per
+// half of a complex multiply-add (op_sel broadcasts, no shuffles): f32 vector peak on gfx950 needs
+// the packed form.  `rot(v)` = (-v.y, v.x) = i v and `rotc(v)` = (v.y, -v.x) = -i v are formed once
+// per vector element and reused across a whole block row / column.
+typedef float v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2 tov2(float2 a) { return v2{a.x, a.y}; }
+__device__ __forceinline__ float2 tof2(v2 a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ v2 rot(v2 v) { return v2{-v.y, v.x}; }
+__device__ __forceinline__ v2 rotc(v2 v) { return v2{v.y, -v.x}; }
+// acc + m * v, given vj = rot(v)
+__device__ __forceinline__ v2 pk_cmac(v2 acc, v2 m, v2 v, v2 vj) {
+    acc = __builtin_elementwise_fma(m.xx, v, acc);
+    return __builtin_elementwise_fma(m.yy, vj, acc);
+}
+// acc + a * conj(b), given aj = rotc(a):  a conj(b) = b.x (a.x, a.y) + b.y (a.y, -a.x)
+__device__ __forceinline__ v2 pk_cmacc(v2 acc, v2 a, v2 aj, v2 b) {
+    acc = __builtin_elementwise_fma(b.xx, a, acc);
+    return __builtin_elementwise_fma(b.yy, aj, acc);
+}
+
 template <int NA>
 struct TrShared {
     float2 colbuf[2][16 * NA];
@@ -79,50 +99,44 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
         sh.taus[u] = tau;
     }
     // v restricted to my rows / my columns (zero above the unit position and beyond D)
-    float2 vr[NA], vc[NA];
-#pragma unroll
-    for (int a = A0; a < NA; ++a) {
-        const int i = 16 * a + ti;
-        float2 x = (i > u && i < D) ? cmul(col[i], sc) : make_float2(0.f, 0.f);
-        if (i == u) x = make_float2(1.f, 0.f);
-        vr[a] = x;
-        const int j = 16 * a + tj;
-        float2 y = (j > u && j < D) ? cmul(col[j], sc) : make_float2(0.f, 0.f);
-        if (j == u) y = make_float2(1.f, 0.f);
-        vc[a] = y;
-    }
+    const v2 scv = tov2(sc), scj = rot(scv);
+    auto vat = [&](int i) -> v2 {
+        v2 x = (i > u && i < D) ? pk_cmac(v2{0.f, 0.f}, tov2(col[i]), scv, scj) : v2{0.f, 0.f};
+        if (i == u) x = v2{1.f, 0.f};
+        return x;
+    };
     // keep the reflector for the Q accumulation: row u of the (consumed) global image
-    if (tid < D) {
-        float2 x = (tid > u) ? cmul(col[tid], sc) : make_float2(0.f, 0.f);
-        if (tid == u) x = make_float2(1.f, 0.f);
-        Mg[(int64_t)u * D + tid] = x;
-    }
+    if (tid < D) Mg[(int64_t)u * D + tid] = tof2(vat(tid));
     if (tr == 0.f && tim == 0.f) return;   // H = I (uniform)
 
-    // p = tau * M v : partial over my columns, summed along the 16 fast lanes
-    float2 pr[NA];
-    float2 dotp = make_float2(0.f, 0.f);
+    v2 vr[NA], vc[NA], vcj[NA];
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
-        float2 acc = make_float2(0.f, 0.f);
+        vr[a] = vat(16 * a + ti);
+        vc[a] = vat(16 * a + tj);
+        vcj[a] = rot(vc[a]);
+    }
+    // p = tau * M v : partial over my columns, summed along the 16 fast lanes
+    const v2 tauv = tov2(tau), tauj = rot(tauv);
+    v2 dotp = {0.f, 0.f};
 #pragma unroll
-        for (int b = A0; b < NA; ++b) {
-            const float2 mm = m[a][b], vv = vc[b];
-            acc.x = fmaf(mm.x, vv.x, fmaf(-mm.y, vv.y, acc.x));
-            acc.y = fmaf(mm.x, vv.y, fmaf(mm.y, vv.x, acc.y));
-        }
+    for (int a = A0; a < NA; ++a) {
+        v2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int b = A0; b < NA; ++b) acc = pk_cmac(acc, tov2(m[a][b]), vc[b], vcj[b]);
         acc.x = row16_sum(acc.x);
         acc.y = row16_sum(acc.y);
-        const float2 p = cmul(tau, acc);
-        pr[a] = p;
+        const v2 p = pk_cmac(v2{0.f, 0.f}, acc, tauv, tauj);   // tau * acc
         if (tj == a) {   // one lane per row publishes p_i and its share of p^H v
-            sh.pbuf[par][16 * a + ti] = p;
-            dotp = cmacc(dotp, p, vr[a]);
+            sh.pbuf[par][16 * a + ti] = tof2(p);
+            // conj(p) v = v.x (p.x, -p.y) + v.y (p.y, p.x)
+            dotp = __builtin_elementwise_fma(vr[a].xx, v2{p.x, -p.y}, dotp);
+            dotp = __builtin_elementwise_fma(vr[a].yy, v2{p.y, p.x}, dotp);
         }
     }
     dotp.x = wave_sum(dotp.x);
     dotp.y = wave_sum(dotp.y);
-    if (lane == 0) sh.dotbuf[par][wave] = dotp;
+    if (lane == 0) sh.dotbuf[par][wave] = tof2(dotp);
     __syncthreads();   // (B) p and the dot partials visible
     float2 dot = sh.dotbuf[par][0];
 #pragma unroll
@@ -131,30 +145,31 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
         dot.y += sh.dotbuf[par][q].y;
     }
     float2 al = cmul(tau, dot);
-    al.x *= -0.5f;
-    al.y *= -0.5f;
-    float2 wr[NA], wc[NA];
+    const v2 alv = v2{-0.5f * al.x, -0.5f * al.y}, alj = rot(alv);
+    // M -= v w^H + w v^H on the active block:  x += (-v_i) conj(w_j) + (-w_i) conj(v_j)
+    v2 wc[NA];
+#pragma unroll
+    for (int b = A0; b < NA; ++b) {
+        const int j = 16 * b + tj;
+        const v2 w = pk_cmac(tov2(sh.pbuf[par][j]), vc[b], alv, alj);   // p_j + alpha v_j
+        wc[b] = (j >= u && j < D) ? w : v2{0.f, 0.f};
+    }
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
-        const int i = 16 * a + ti, j = 16 * a + tj;
-        const float2 t1 = cmul(al, vr[a]);
-        wr[a] = (i >= u && i < D) ? make_float2(pr[a].x + t1.x, pr[a].y + t1.y) : make_float2(0.f, 0.f);
-        const float2 pj = sh.pbuf[par][j];
-        const float2 t2 = cmul(al, vc[a]);
-        wc[a] = (j >= u && j < D) ? make_float2(pj.x + t2.x, pj.y + t2.y) : make_float2(0.f, 0.f);
-    }
-    // M -= v w^H + w v^H on the active block
-#pragma unroll
-    for (int a = A0; a < NA; ++a)
+        const int i = 16 * a + ti;
+        const v2 w = pk_cmac(tov2(sh.pbuf[par][i]), vr[a], alv, alj);   // p_i + alpha v_i
+        const v2 wra = (i >= u && i < D) ? -w : v2{0.f, 0.f};
+        const v2 vra = -vr[a];
+        const v2 wraj = rotc(wra), vraj = rotc(vra);
 #pragma unroll
         for (int b = A0; b < NA; ++b) {
-            const float2 t1 = cmulc(vr[a], wc[b]), t2 = cmulc(wr[a], vc[b]);
-            float2 mm = m[a][b];
-            mm.x -= t1.x + t2.x;
-            mm.y -= t1.y + t2.y;
-            if (a == b && ti == tj) mm.y = 0.f;
-            m[a][b] = mm;
+            v2 x = tov2(m[a][b]);
+            x = pk_cmacc(x, vra, vraj, wc[b]);
+            x = pk_cmacc(x, wra, wraj, vc[b]);
+            if (a == b && ti == tj) x.y = 0.f;
+            m[a][b] = tof2(x);
         }
+    }
 }
 
 // P <- P (I - conj(tau) v v^H) for the reflector with unit entry u, 16*A0 <= u < 16*(A0+1)
@@ -164,31 +179,25 @@ __device__ __forceinline__ void q_step(float2 (&m)[NA][NA], const TrShared<NA> &
     const int tj = threadIdx.x & 15;
     const float2 tau = sh.taus[u];
     if (tau.x == 0.f && tau.y == 0.f) return;
-    float2 vc[NA];
+    v2 vc[NA], vj[NA];
 #pragma unroll
     for (int b = A0; b < NA; ++b) {
         const int j = 16 * b + tj;
-        vc[b] = (j < D) ? Mg[(int64_t)u * D + j] : make_float2(0.f, 0.f);
+        vc[b] = (j < D) ? tov2(Mg[(int64_t)u * D + j]) : v2{0.f, 0.f};
+        vj[b] = rot(vc[b]);
     }
     const float2 ctau = make_float2(tau.x, -tau.y);
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
-        float2 y = make_float2(0.f, 0.f);
+        v2 y = {0.f, 0.f};
 #pragma unroll
-        for (int b = A0; b < NA; ++b) {
-            const float2 pp = m[a][b], vv = vc[b];
-            y.x = fmaf(pp.x, vv.x, fmaf(-pp.y, vv.y, y.x));
-            y.y = fmaf(pp.x, vv.y, fmaf(pp.y, vv.x, y.y));
-        }
+        for (int b = A0; b < NA; ++b) y = pk_cmac(y, tov2(m[a][b]), vc[b], vj[b]);
         y.x = row16_sum(y.x);
         y.y = row16_sum(y.y);
-        const float2 ty = cmul(ctau, y);
+        const float2 ty = cmul(ctau, tof2(y));
+        const v2 nty = v2{-ty.x, -ty.y}, ntyj = rotc(nty);
 #pragma unroll
-        for (int b = A0; b < NA; ++b) {
-            const float2 t = cmulc(ty, vc[b]);   // conj(tau) y conj(v_b)
-            m[a][b].x -= t.x;
-            m[a][b].y -= t.y;
-        }
+        for (int b = A0; b < NA; ++b) m[a][b] = tof2(pk_cmacc(tov2(m[a][b]), nty, ntyj, vc[b]));   // -= conj(tau) y conj(v_b)
     }
 }
 
