@@ -56,7 +56,8 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
     int *src = perm + NP;
     int *org = src + NP;
     int *rnk = org + NP;
-    DcRot *rot = reinterpret_cast<DcRot *>(rnk + NP);          // [NP]
+    int *cidx = rnk + NP;                                      // source column (block-local) of merged position p
+    DcRot *rot = reinterpret_cast<DcRot *>(cidx + NP);         // [NP]
     float *leafZ = reinterpret_cast<float *>(rot + NP);         // [nleaf][DC_MAXLS * DC_MAXLS]
     float *leafD = leafZ + (size_t)max(1, n / DC_LS) * DC_MAXLS * DC_MAXLS;   // [nleaf][2 * DC_MAXLS]
 
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
                 }
                 rnk[a + p] = r;
                 lamn[a + r] = v;
+                cidx[a + p] = perm[a + src[a + p]];
             }
         }
         __syncthreads();
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
         //     WTdst[rank(j)][i] = sum_kk U[kk][j] * WTsrc[col(src[kk])][i]   (MFMA, waves take tiles)
         if (act) {
             for (int p = k + (tl / 32); p < nn; p += max(1, ts / 32)) {   // 32 lanes per column copy
-                const float *xs = Ws + (int64_t)(a + perm[a + src[a + p]]) * n + a;
+                const float *xs = Ws + (int64_t)(a + cidx[a + p]) * n + a;
                 float *xd = Wd + (int64_t)(a + rnk[a + p]) * n + a;
                 for (int i = (ts >= 32 ? (tl & 31) : tl); i < nn; i += (ts >= 32 ? 32 : ts)) xd[i] = xs[i];
             }
@@ -261,16 +263,23 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
                     const int j0 = (t / tn) * 32, i0 = (t % tn) * 32;
                     const bool jv = (j0 + r) < mk, iv = (i0 + r) < mnn;
                     f32x16 acc = {0};
-                    for (int k0 = 0; k0 < mk; k0 += 2) {
-                        const int kq = k0 + kh;
-                        const bool kv = kq < mk;
-                        const int kc = kv ? kq : 0;
-                        // A[j][kk] = U[kk][j]; B[kk][i] = WTsrc[col(src[kk])][i]
-                        float av = U[(int64_t)(ma + kc) * n + ma + (jv ? j0 + r : 0)];
-                        float bv = Ws[(int64_t)(ma + perm[ma + src[ma + kc]]) * n + ma + (iv ? i0 + r : 0)];
-                        av = (kv && jv) ? av : 0.f;
-                        bv = (kv && iv) ? bv : 0.f;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                    const int jo = jv ? j0 + r : 0, io = iv ? i0 + r : 0;
+                    for (int k0 = 0; k0 < mk; k0 += 16) {   // 8 K-steps per trip: loads first, then the MFMAs
+                        float av[8], bv[8];
+#pragma unroll
+                        for (int s8 = 0; s8 < 8; ++s8) {
+                            const int kq = k0 + 2 * s8 + kh;
+                            const bool kv = kq < mk;
+                            const int kc = kv ? kq : 0;
+                            // A[j][kk] = U[kk][j]; B[kk][i] = WTsrc[col(kk)][i]
+                            const float a_ = U[(int64_t)(ma + kc) * n + ma + jo];
+                            const float b_ = Ws[(int64_t)(ma + cidx[ma + kc]) * n + ma + io];
+                            av[s8] = (kv && jv) ? a_ : 0.f;
+                            bv[s8] = (kv && iv) ? b_ : 0.f;
+                        }
+#pragma unroll
+                        for (int s8 = 0; s8 < 8; ++s8)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s8], bv[s8], acc, 0, 0, 0);
                     }
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
@@ -373,7 +382,7 @@ size_t dc_lds_bytes(int n) {
     const size_t nleaf = (size_t)(n / DC_LS > 0 ? n / DC_LS : 1);
     size_t leaf = nleaf * DC_MAXLS * DC_MAXLS + nleaf * 2 * DC_MAXLS;
     if (leaf < 32 * 33) leaf = 32 * 33;   // the final transpose reuses the leaf scratch as a tile
-    return sizeof(float) * 11 * NP + sizeof(int) * 4 * NP + sizeof(DcRot) * NP + sizeof(float) * leaf;
+    return sizeof(float) * 11 * NP + sizeof(int) * 5 * NP + sizeof(DcRot) * NP + sizeof(float) * leaf;
 }
 
 int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st) {

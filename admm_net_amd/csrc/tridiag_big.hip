@@ -11,7 +11,9 @@
 //   mirrored part along ti (in-wave swap + one 32 KB LDS pass);  3 barriers per reflector.
 // The explicit Q (not Hermitian: 512 KB) is formed by a second kernel, ungtr_big_kernel, as
 // P = Q^H with its ROWS split over two workgroups (rows of P are independent under
-// P <- P H^H), barrier free.  Same mathematics as tridiag_reg.hip (LAPACK chetd2 + cung2l,
+// P <- P H^H), barrier free, in packed (v_pk_fma_f32) complex arithmetic.  (The packed form was
+// also tried in the tridiagonalisation kernel below: its extra live vectors raised the spill
+// count from 57 to 178 VGPRs and made it 30 % slower, so that kernel keeps scalar FMAs.)  Same mathematics as tridiag_reg.hip (LAPACK chetd2 + cung2l,
 // first half of torch.linalg.eigh at /root/reference/admm_net.py:303).
 #include "common.h"
 
@@ -114,36 +116,36 @@ __device__ __forceinline__ void tb_step(float2 (&m)[tb_nslot(NA)], float2 *__res
     //      row part  sum_{j <= blk(i)} M_ij v_j  (reduce over tj, the 32 fast lanes), then the
     //      mirrored part  sum_{i > blk(j)} conj(M_ij) v_i  (reduce over ti: in-wave swap + LDS)
     {
-        v2 vc[NA];
+        float2 vc[NA];
 #pragma unroll
-        for (int b = A0; b < NA; ++b) vc[b] = b_tov2(vat(32 * b + tj));
+        for (int b = A0; b < NA; ++b) vc[b] = vat(32 * b + tj);
 #pragma unroll
         for (int a = A0; a < NA; ++a) {
-            v2 acc = {0.f, 0.f};
+            float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
-            for (int b = A0; b <= a; ++b) acc = b_cmac(acc, b_tov2(TB_GET(a, b)), vc[b], b_rot(vc[b]));
+            for (int b = A0; b <= a; ++b) {
+                const float2 x = TB_GET(a, b);
+                acc.x = fmaf(x.x, vc[b].x, fmaf(-x.y, vc[b].y, acc.x));
+                acc.y = fmaf(x.x, vc[b].y, fmaf(x.y, vc[b].x, acc.y));
+            }
             acc.x = row32_sum(acc.x);
             acc.y = row32_sum(acc.y);
-            if (tj == a) sh.prow[32 * a + ti] = b_tof2(acc);
+            if (tj == a) sh.prow[32 * a + ti] = acc;
             __builtin_amdgcn_sched_barrier(0);   // keep the block-row loads inside their iteration (VGPR budget)
         }
     }
     {
-        v2 vr[NA];
+        float2 vr[NA];
 #pragma unroll
-        for (int a = A0; a < NA; ++a) vr[a] = b_tov2(vat(32 * a + ti));
+        for (int a = A0; a < NA; ++a) vr[a] = vat(32 * a + ti);
 #pragma unroll
         for (int b = A0; b < NA - 1; ++b) {
-            v2 t = {0.f, 0.f};
+            float2 t = make_float2(0.f, 0.f);
 #pragma unroll
-            for (int a = b + 1; a < NA; ++a) {   // conj(M_ij) v_i = x.x (v.x, v.y) + x.y (v.y, -v.x) -> row j
-                const v2 x = b_tov2(TB_GET(a, b));
-                t = __builtin_elementwise_fma(x.xx, vr[a], t);
-                t = __builtin_elementwise_fma(x.yy, b_rotc(vr[a]), t);
-            }
+            for (int a = b + 1; a < NA; ++a) t = cmacc(t, TB_GET(a, b), vr[a]);   // conj(M_ij) v_i -> row j
             t.x += __shfl_xor(t.x, 32, 64);
             t.y += __shfl_xor(t.y, 32, 64);
-            if (lane < 32) sh.cpart[wave][32 * b + tj] = b_tof2(t);
+            if (lane < 32) sh.cpart[wave][32 * b + tj] = t;
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -183,26 +185,24 @@ __device__ __forceinline__ void tb_step(float2 (&m)[tb_nslot(NA)], float2 *__res
         const float2 p = sh.pfull[i], t = cmul(al, v);
         return make_float2(p.x + t.x, p.y + t.y);
     };
-    v2 vc[NA], wc[NA];
+    float2 vc[NA], wc[NA];
 #pragma unroll
     for (int b = A0; b < NA; ++b) {
-        const float2 v = vat(32 * b + tj);
-        vc[b] = b_tov2(v);
-        wc[b] = b_tov2(wat(32 * b + tj, v));
+        vc[b] = vat(32 * b + tj);
+        wc[b] = wat(32 * b + tj, vc[b]);
     }
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
-        const float2 vf = vat(32 * a + ti);
-        const float2 wf = wat(32 * a + ti, vf);
-        const v2 vra = v2{-vf.x, -vf.y}, wra = v2{-wf.x, -wf.y};   // x += (-v_i) conj(w_j) + (-w_i) conj(v_j)
-        const v2 vraj = b_rotc(vra), wraj = b_rotc(wra);
+        const float2 vra = vat(32 * a + ti);
+        const float2 wra = wat(32 * a + ti, vra);
 #pragma unroll
         for (int b = A0; b <= a; ++b) {
-            v2 x = b_tov2(TB_GET(a, b));
-            x = b_cmacc(x, vra, vraj, wc[b]);
-            x = b_cmacc(x, wra, wraj, vc[b]);
+            const float2 t1 = cmulc(vra, wc[b]), t2 = cmulc(wra, vc[b]);
+            float2 x = TB_GET(a, b);
+            x.x -= t1.x + t2.x;
+            x.y -= t1.y + t2.y;
             if (a == b && ti == tj) x.y = 0.f;
-            TB_SET(a, b, b_tof2(x));
+            TB_SET(a, b, x);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
