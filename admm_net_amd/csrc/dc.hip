@@ -12,6 +12,9 @@
 //
 // Layouts: eigenvector blocks are kept transposed, WT[j][i] = W[i][j] (j = eigenvalue index), in
 // two ping-pong n x n global buffers per matrix (L2 resident); U of every merge goes to a third.
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 #include "dc_core.h"
 
@@ -34,12 +37,24 @@ struct DcShared {
 __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__restrict__ dT,
                                                         const float *__restrict__ eT, float *__restrict__ Wbuf,
                                                         float *__restrict__ wout, float *__restrict__ w0out,
-                                                        int *__restrict__ logn, int32_t *__restrict__ status) {
+                                                        int *__restrict__ logn, int32_t *__restrict__ status,
+                                                        unsigned long long *__restrict__ ptime) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ DcShared sh;
     const int tid = threadIdx.x;
     const int64_t bm = blockIdx.x;
     const int NP = (n + 3) & ~3;
+    // developer phase timer (ADMMNET_DC_TIMING=1): cycles of workgroup thread 0 between barriers
+    long long t_prev = ptime ? clock64() : 0;
+    int lvl = 0;
+    auto mark = [&](int id) {
+        if (ptime && tid == 0) {
+            const long long t_now = clock64();
+            atomicAdd(&ptime[id], (unsigned long long)(t_now - t_prev));
+            if (id >= 2 && id <= 8) atomicAdd(&ptime[16 + 8 * min(lvl, 5) + id - 2], (unsigned long long)(t_now - t_prev));
+            t_prev = t_now;
+        }
+    };
     // LDS carve (floats / ints of length NP each)
     float *lam = reinterpret_cast<float *>(smem);
     float *e0 = lam + NP;
@@ -81,6 +96,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
     // the next level reads the (zero) off-diagonal blocks of the pair it merges
     for (int64_t i = tid; i < (int64_t)2 * n * n; i += DC_THREADS) WA[i] = 0.f;
     __syncthreads();
+    mark(0);
     // tear: d[k-1] -= |e[k-1]|, d[k] -= |e[k-1]| at every leaf boundary k
     for (int b = 1 + tid; b < nleaf; b += DC_THREADS) {
         const int k = b * DC_LS;
@@ -122,6 +138,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
         }
     }
     __syncthreads();
+    mark(1);
 
     // ---- merge levels
     int nblk = nleaf, cb = 0;
@@ -165,6 +182,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
             }
         }
         __syncthreads();
+        mark(2);
         // P2: deflation scan (one thread per merge)
         if (act && tl == 0) {
             int k = 0, nr = 0;
@@ -174,6 +192,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
             for (int p = k; p < nn; ++p) vals[a + p] = dl[a + p];
         }
         __syncthreads();
+        mark(3);
         const int k = act ? sh.kk[team] : 0;
         // P3: deflation rotations on the source columns (thread-private rows i) + secular roots
         if (act) {
@@ -198,6 +217,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
             }
         }
         __syncthreads();
+        mark(4);
         // P4: Loewner z-hat, final (ascending, stable) positions
         if (act) {
             for (int i = tl; i < k; i += ts) zh[a + i] = lowner_zhat(k, i, dl + a, zl + a, org + a, tau + a);
@@ -214,6 +234,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
             }
         }
         __syncthreads();
+        mark(5);
         // P5: normalised eigenvectors of the rank-one update, U[kk][j] (kk pole, j root)
         if (act) {
             for (int j = tl; j < k; j += ts) {
@@ -231,6 +252,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
             }
         }
         __syncthreads();
+        mark(6);
         // P6: new blocks.  Deflated columns are copied, the others come from the GEMM
         //     WTdst[rank(j)][i] = sum_kk U[kk][j] * WTsrc[col(src[kk])][i]   (MFMA, waves take tiles)
         if (act) {
@@ -291,6 +313,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
             }
         }
         __syncthreads();
+        mark(7);
         // P7: commit eigenvalues and block boundaries
         for (int i = tid; i < n; i += DC_THREADS) lam[i] = lamn[i];
         if (tid == 0) {
@@ -300,8 +323,10 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
             sh.bnd[cb ^ 1][o] = n;
         }
         __syncthreads();
+        mark(8);
         nblk = nm + (odd ? 1 : 0);
         cb ^= 1;
+        ++lvl;
         float *tmp = Ws;
         Ws = Wd;
         Wd = tmp;
@@ -332,6 +357,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
             }
         }
     }
+    mark(9);
     if (tid == 0) {
         logn[bm * 2 + 0] = 0;
         logn[bm * 2 + 1] = sh.fail ? 1 : 0;
@@ -395,9 +421,30 @@ int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st) 
     const size_t lds = dc_lds_bytes(n);
     ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dc_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const bool timing = getenv("ADMMNET_DC_TIMING") != nullptr;   // developer aid, never on by default
+    unsigned long long *ptime = nullptr;
+    if (timing) {
+        ADMM_HIP(hipMalloc(&ptime, 64 * sizeof(unsigned long long)));
+        ADMM_HIP(hipMemsetAsync(ptime, 0, 64 * sizeof(unsigned long long), st));
+    }
     hipLaunchKernelGGL(dc_kernel, dim3((unsigned)nb), dim3(DC_THREADS), lds, st, n, ws.dT, ws.eT, ws.Wdc, ws.w,
-                       ws.w0, ws.logn, status);
+                       ws.w0, ws.logn, status, ptime);
     ADMM_HIP(hipGetLastError());
+    if (timing) {
+        unsigned long long h[64];
+        ADMM_HIP(hipMemcpyAsync(h, ptime, sizeof(h), hipMemcpyDeviceToHost, st));
+        ADMM_HIP(hipStreamSynchronize(st));
+        ADMM_HIP(hipFree(ptime));
+        static const char *nm[10] = {"init", "leaves", "P1 sort", "P2 scan", "P3 rot+secular", "P4 zhat+rank",
+                                     "P5 U", "P6 copy+gemm", "P7 commit", "final transpose"};
+        fprintf(stderr, "[dc timing] n=%d nb=%lld  mean cycles per workgroup:\n", n, (long long)nb);
+        for (int i = 0; i < 10; ++i) fprintf(stderr, "   %-16s %10.0f\n", nm[i], (double)h[i] / (double)nb);
+        for (int l = 0; l < 6; ++l) {
+            fprintf(stderr, "   level %d:", l);
+            for (int q = 0; q < 7; ++q) fprintf(stderr, " %8.0f", (double)h[16 + 8 * l + q] / (double)nb);
+            fprintf(stderr, "\n");
+        }
+    }
     return ADMMNET_OK;
 }
 

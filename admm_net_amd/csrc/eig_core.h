@@ -82,6 +82,17 @@ HD float sign_of(float a, float b) { return b >= 0.f ? fabsf(a) : -fabsf(a); }
 //   H = I - tau * v v^H, v = [1; x*scale],  H^H [alpha; x] = [beta; 0], beta real.
 // Given alpha (ar, ai) and xnorm2 = ||x||^2, returns beta, tau and the scale
 // to apply to x.  tau == 0 means H = I.
+// 1 / x: v_rcp_f32 plus one Newton step on the device (well under 1 ulp; the IEEE division sequence
+// costs ~10 instructions and householder_c sits on the serial path of every reflector)
+HD float recip_nr(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+#else
+    return 1.0f / x;
+#endif
+}
+
 HD void householder_c(float ar, float ai, float xnorm2, float &beta, float &tr, float &ti,
                       float &sr, float &si) {
     if (xnorm2 == 0.f && ai == 0.f) {
@@ -90,13 +101,14 @@ HD void householder_c(float ar, float ai, float xnorm2, float &beta, float &tr, 
     }
     float nrm = sqrtf(ar * ar + ai * ai + xnorm2);
     beta = -sign_of(nrm, ar);
-    tr = (beta - ar) / beta;
-    ti = -ai / beta;
+    const float ib = recip_nr(beta);
+    tr = (beta - ar) * ib;
+    ti = -ai * ib;
     // scale = 1 / (alpha - beta)
     float dr = ar - beta, di = ai;
-    float den = dr * dr + di * di;
-    sr = dr / den;
-    si = -di / den;
+    const float iden = recip_nr(dr * dr + di * di);
+    sr = dr * iden;
+    si = -di * iden;
 }
 
 // Implicit-shift QL (EISPACK tql2 / Numerical Recipes tqli organisation) on a

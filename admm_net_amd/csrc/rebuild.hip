@@ -45,7 +45,8 @@ __global__ __launch_bounds__(RB_THREADS) void rebuild_kernel(int D, const float 
     const int64_t b = blockIdx.x;
     float *fs = reinterpret_cast<float *>(smem);   // [n+1] f(lambda)
     float *w0f = fs + ((n + 4) & ~3);              // [n+1] w0 * f
-    float *rowb = w0f + ((n + 4) & ~3);            // [2D] last-row staging
+    float *z0s = w0f + ((n + 4) & ~3);             // [n+1] w0
+    float *rowb = z0s + ((n + 4) & ~3);            // [2D] last-row staging
     float *redb = rowb + 2 * D;                    // [8]
     const LayerLayout L{D};
     const float thr = lw[S_THR];
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(RB_THREADS) void rebuild_kernel(int D, const float 
         }
         fs[c] = f;
         w0f[c] = z0 * f;
+        z0s[c] = z0;
     }
     __syncthreads();
 
@@ -121,6 +123,7 @@ __global__ __launch_bounds__(RB_THREADS) void rebuild_kernel(int D, const float 
     // ---- arrow row (perm row 0 = original row D): G'[0][j] = sum_c w0_c f_c conj(V[j][c])
     for (int rho = tid; rho < 2 * D; rho += RB_THREADS) {
         float a = 0.f;
+#pragma unroll 8
         for (int c = 0; c < n; ++c) a = fmaf(w0f[c], VT[(int64_t)c * pitch + rho], a);
         rowb[rho] = a;
     }
@@ -133,15 +136,15 @@ __global__ __launch_bounds__(RB_THREADS) void rebuild_kernel(int D, const float 
         const float dr = gr - p.x, di = gim + p.y;
         acc2 += 2.f * (dr * dr + di * di);
     }
-    if (tid == 0) {
+    if (wave == 0) {   // corner: G'[0][0] = sum_c f_c w0_c^2
         float g00 = 0.f;
-        for (int c = 0; c < n; ++c) {
-            const float z0 = w0v[b * n + c];
-            g00 = fmaf(w0f[c], z0, g00);
+        for (int c = lane; c < n; c += 64) g00 = fmaf(w0f[c], z0s[c], g00);
+        g00 = wave_sum(g00);
+        if (lane == 0) {
+            Gb[(int64_t)D * n + D] = make_float2(g00, 0.f);
+            const float d = g00 - lw[S_CORNER_Z];
+            acc2 += d * d;
         }
-        Gb[(int64_t)D * n + D] = make_float2(g00, 0.f);
-        const float d = g00 - lw[S_CORNER_Z];
-        acc2 += d * d;
     }
     acc2 = wave_sum(acc2);
     if (lane == 0) redb[wave] = acc2;
@@ -174,7 +177,7 @@ int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const 
     ProfScope _prof(KC_REBUILD, st);
     if (nb <= 0) return ADMMNET_OK;
     const int n = D + 1;
-    const size_t lds = sizeof(float) * (2 * ((n + 4) & ~3) + 2 * D + 8);
+    const size_t lds = sizeof(float) * (3 * ((n + 4) & ~3) + 2 * D + 8);
     hipLaunchKernelGGL(rebuild_kernel, dim3((unsigned)nb), dim3(RB_THREADS), lds, st, D, lw, ws.VT, ws.w,
                        ws.w0, phi, h, G, rn);
     ADMM_HIP(hipGetLastError());

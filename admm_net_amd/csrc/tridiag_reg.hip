@@ -18,16 +18,29 @@ namespace admmnet {
 
 constexpr int TR_THREADS = 256;
 
+// DPP lane exchanges: no LDS traffic, no barrier.  CTRL 0x121/2/4/8 = row_ror:1/2/4/8 (rotate inside
+// each row of 16 lanes), 0x142 / 0x143 = row_bcast:15 / row_bcast:31 (last lane of a row -> next row(s)).
+template <int CTRL, int ROWMASK = 0xF>
+__device__ __forceinline__ float dpp_get(float x) {
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, false));
+}
 // sum over the 16 lanes of a DPP row; every lane of the row receives the total
 __device__ __forceinline__ float row16_sum(float x) {
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, false));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, false));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xF, 0xF, false));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xF, 0xF, false));
+    x += dpp_get<0x128>(x);
+    x += dpp_get<0x124>(x);
+    x += dpp_get<0x122>(x);
+    x += dpp_get<0x121>(x);
     return x;
 }
+// sum over the whole wave as a wave-uniform value (row totals chained through row_bcast, then a readlane)
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+    x = row16_sum(x);
+    x += dpp_get<0x142, 0xA>(x);   // rows 1, 3 += row 0, 2
+    x += dpp_get<0x143, 0xC>(x);   // rows 2, 3 += rows 0 + 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
 
-// Shared state of one workgroup's LDS vectors.
 // Complex arithmetic on (re, im) register pairs written so that hipcc emits ONE v_pk_fma_f32 per
 // half of a complex multiply-add (op_sel broadcasts, no shuffles): f32 vector peak on gfx950 needs
 // the packed form.  `rot(v)` = (-v.y, v.x) = i v and `rotc(v)` = (v.y, -v.x) = -i v are formed once
@@ -47,12 +60,28 @@ __device__ __forceinline__ v2 pk_cmacc(v2 acc, v2 a, v2 aj, v2 b) {
     acc = __builtin_elementwise_fma(b.xx, a, acc);
     return __builtin_elementwise_fma(b.yy, aj, acc);
 }
+// stage-wise row reduction of NA complex values: the NA chains interleave, so no DPP hazard stalls
+template <int NA, int A0>
+__device__ __forceinline__ void row16_sum_all(v2 (&acc)[NA]) {
+#pragma unroll
+    for (int a = A0; a < NA; ++a) { acc[a].x += dpp_get<0x128>(acc[a].x); acc[a].y += dpp_get<0x128>(acc[a].y); }
+#pragma unroll
+    for (int a = A0; a < NA; ++a) { acc[a].x += dpp_get<0x124>(acc[a].x); acc[a].y += dpp_get<0x124>(acc[a].y); }
+#pragma unroll
+    for (int a = A0; a < NA; ++a) { acc[a].x += dpp_get<0x122>(acc[a].x); acc[a].y += dpp_get<0x122>(acc[a].y); }
+#pragma unroll
+    for (int a = A0; a < NA; ++a) { acc[a].x += dpp_get<0x121>(acc[a].x); acc[a].y += dpp_get<0x121>(acc[a].y); }
+}
 
+// LDS vectors of one workgroup (double-buffered by reflector parity: one barrier separates a write
+// from the reads of the previous use)
 template <int NA>
 struct TrShared {
-    float2 colbuf[2][16 * NA];
-    float2 pbuf[2][16 * NA];
+    float2 colbuf[2][16 * NA];   // x = column below the unit position, ZERO at i <= u and i >= D
+    float2 pbuf[2][16 * NA];     // p = tau M v
     float2 dotbuf[2][4];
+    float2 head[2];              // alpha = column entry at the unit position
+    float dprev[2];              // finished diagonal entry d[u]
     float2 taus[16 * NA];
 };
 
@@ -67,76 +96,95 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
     const int tj = tid & 15, ti = tid >> 4;
     const int par = u & 1;
     if (u == 0) {
-        for (int i = tid; i < 16 * NA; i += TR_THREADS) sh.colbuf[0][i] = (i < D) ? ag[i] : make_float2(0.f, 0.f);
+        for (int i = tid; i < 16 * NA; i += TR_THREADS) {
+            const float2 x = (i < D) ? ag[i] : make_float2(0.f, 0.f);
+            sh.colbuf[0][i] = (i > 0) ? x : make_float2(0.f, 0.f);
+            if (i == 0) sh.head[0] = x;
+        }
     } else {
         const int k = u - 1;
         if (tj == (k & 15)) {
             // column k lives in block (k >> 4), which is A0 or (for u = 16 A0) A0 - 1
-            if ((k >> 4) == A0) {
+            constexpr int AP = A0 > 0 ? A0 - 1 : 0;
+            const bool cur = (k >> 4) == A0;
 #pragma unroll
-                for (int a = 0; a < NA; ++a) sh.colbuf[par][16 * a + ti] = m[a][A0];
-            } else {
-#pragma unroll
-                for (int a = 0; a < NA; ++a) sh.colbuf[par][16 * a + ti] = m[a][A0 > 0 ? A0 - 1 : 0];
+            for (int a = AP; a < NA; ++a) {
+                const int i = 16 * a + ti;
+                const float2 x = cur ? m[a][A0] : m[a][AP];
+                sh.colbuf[par][i] = (i > u) ? x : make_float2(0.f, 0.f);
+                if (i == u) sh.head[par] = x;
+                if (i == k) sh.dprev[par] = x.x;
             }
         }
     }
     __syncthreads();   // (A) column visible
     const float2 *col = sh.colbuf[par];
     float pn = 0.f;
-    for (int i = u + 1 + lane; i < D; i += 64) {
-        const float2 x = col[i];
-        pn += x.x * x.x + x.y * x.y;
+#pragma unroll
+    for (int q = 0; q < (16 * NA + 63) / 64; ++q) {
+        const int i = lane + 64 * q;
+        if ((16 * NA) % 64 == 0 || i < 16 * NA) {
+            const float2 x = col[i];
+            pn += x.x * x.x + x.y * x.y;
+        }
     }
-    const float xn2 = wave_sum(pn);
-    const float2 alpha = col[u];
+    const float xn2 = wave_sum_dpp(pn);
+    const float2 alpha = sh.head[par];
     float beta, tr, tim, sr, si;
     householder_c(alpha.x, alpha.y, xn2, beta, tr, tim, sr, si);
     const float2 tau = make_float2(tr, tim), sc = make_float2(sr, si);
     if (tid == 0) {
         ecol[u] = beta;
-        dcol[u] = (u == 0) ? corner : col[u - 1].x;
+        dcol[u] = (u == 0) ? corner : sh.dprev[par];
         sh.taus[u] = tau;
     }
-    // v restricted to my rows / my columns (zero above the unit position and beyond D)
+    // v = scale * x, one at the unit position (x is already zero above it and beyond D)
     const v2 scv = tov2(sc), scj = rot(scv);
-    auto vat = [&](int i) -> v2 {
-        v2 x = (i > u && i < D) ? pk_cmac(v2{0.f, 0.f}, tov2(col[i]), scv, scj) : v2{0.f, 0.f};
-        if (i == u) x = v2{1.f, 0.f};
-        return x;
-    };
     // keep the reflector for the Q accumulation: row u of the (consumed) global image
-    if (tid < D) Mg[(int64_t)u * D + tid] = tof2(vat(tid));
+    if (tid < D) {
+        v2 x = pk_cmac(v2{0.f, 0.f}, tov2(col[tid]), scv, scj);
+        if (tid == u) x = v2{1.f, 0.f};
+        Mg[(int64_t)u * D + tid] = tof2(x);
+    }
     if (tr == 0.f && tim == 0.f) return;   // H = I (uniform)
 
     v2 vr[NA], vc[NA], vcj[NA];
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
-        vr[a] = vat(16 * a + ti);
-        vc[a] = vat(16 * a + tj);
+        vr[a] = pk_cmac(v2{0.f, 0.f}, tov2(col[16 * a + ti]), scv, scj);
+        vc[a] = pk_cmac(v2{0.f, 0.f}, tov2(col[16 * a + tj]), scv, scj);
+        if (a == A0) {   // the unit position can only sit in the first active block
+            if (16 * a + ti == u) vr[a] = v2{1.f, 0.f};
+            if (16 * a + tj == u) vc[a] = v2{1.f, 0.f};
+        }
         vcj[a] = rot(vc[a]);
     }
-    // p = tau * M v : partial over my columns, summed along the 16 fast lanes
-    const v2 tauv = tov2(tau), tauj = rot(tauv);
-    v2 dotp = {0.f, 0.f};
+    // p = tau * M v : partial over my columns, summed along the 16 fast lanes (all lanes of a row
+    // of the thread grid end up with the p of their matrix rows)
+    v2 pr[NA];
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
         v2 acc = {0.f, 0.f};
 #pragma unroll
         for (int b = A0; b < NA; ++b) acc = pk_cmac(acc, tov2(m[a][b]), vc[b], vcj[b]);
-        acc.x = row16_sum(acc.x);
-        acc.y = row16_sum(acc.y);
-        const v2 p = pk_cmac(v2{0.f, 0.f}, acc, tauv, tauj);   // tau * acc
-        if (tj == a) {   // one lane per row publishes p_i and its share of p^H v
-            sh.pbuf[par][16 * a + ti] = tof2(p);
-            // conj(p) v = v.x (p.x, -p.y) + v.y (p.y, p.x)
-            dotp = __builtin_elementwise_fma(vr[a].xx, v2{p.x, -p.y}, dotp);
-            dotp = __builtin_elementwise_fma(vr[a].yy, v2{p.y, p.x}, dotp);
-        }
+        pr[a] = acc;
     }
-    dotp.x = wave_sum(dotp.x);
-    dotp.y = wave_sum(dotp.y);
-    if (lane == 0) sh.dotbuf[par][wave] = tof2(dotp);
+    row16_sum_all<NA, A0>(pr);
+    const v2 tauv = tov2(tau), tauj = rot(tauv);
+    v2 dotp = {0.f, 0.f}, psel = {0.f, 0.f};
+#pragma unroll
+    for (int a = A0; a < NA; ++a) {
+        pr[a] = pk_cmac(v2{0.f, 0.f}, pr[a], tauv, tauj);   // tau * acc
+        // conj(p) v = v.x (p.x, -p.y) + v.y (p.y, p.x); every lane of the 16 adds the same term,
+        // the total is scaled by 1/16 below (exact)
+        dotp = __builtin_elementwise_fma(vr[a].xx, v2{pr[a].x, -pr[a].y}, dotp);
+        dotp = __builtin_elementwise_fma(vr[a].yy, v2{pr[a].y, pr[a].x}, dotp);
+        psel = (tj == a) ? pr[a] : psel;
+    }
+    if (tj >= A0 && tj < NA) sh.pbuf[par][16 * tj + ti] = tof2(psel);   // lane a of a row publishes p of block row a
+    dotp.x = wave_sum_dpp(dotp.x);
+    dotp.y = wave_sum_dpp(dotp.y);
+    if (lane == 0) sh.dotbuf[par][wave] = make_float2(dotp.x * 0.0625f, dotp.y * 0.0625f);
     __syncthreads();   // (B) p and the dot partials visible
     float2 dot = sh.dotbuf[par][0];
 #pragma unroll
@@ -147,18 +195,21 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
     float2 al = cmul(tau, dot);
     const v2 alv = v2{-0.5f * al.x, -0.5f * al.y}, alj = rot(alv);
     // M -= v w^H + w v^H on the active block:  x += (-v_i) conj(w_j) + (-w_i) conj(v_j)
+    // (w = p + alpha v, zero on the finished rows / columns i < u, which only block A0 can hold)
     v2 wc[NA];
 #pragma unroll
     for (int b = A0; b < NA; ++b) {
         const int j = 16 * b + tj;
-        const v2 w = pk_cmac(tov2(sh.pbuf[par][j]), vc[b], alv, alj);   // p_j + alpha v_j
-        wc[b] = (j >= u && j < D) ? w : v2{0.f, 0.f};
+        v2 w = pk_cmac(tov2(sh.pbuf[par][j]), vc[b], alv, alj);   // p_j + alpha v_j
+        if (b == A0) w = (j >= u) ? w : v2{0.f, 0.f};
+        wc[b] = w;
     }
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
         const int i = 16 * a + ti;
-        const v2 w = pk_cmac(tov2(sh.pbuf[par][i]), vr[a], alv, alj);   // p_i + alpha v_i
-        const v2 wra = (i >= u && i < D) ? -w : v2{0.f, 0.f};
+        v2 w = pk_cmac(pr[a], vr[a], alv, alj);   // p_i + alpha v_i
+        if (a == A0) w = (i >= u) ? w : v2{0.f, 0.f};
+        const v2 wra = -w;
         const v2 vra = -vr[a];
         const v2 wraj = rotc(wra), vraj = rotc(vra);
 #pragma unroll
@@ -172,33 +223,52 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
     }
 }
 
-// P <- P (I - conj(tau) v v^H) for the reflector with unit entry u, 16*A0 <= u < 16*(A0+1)
+// reflector u restricted to my columns (blocks b >= B0), from the global image
+// (float2 storage: arrays of ext_vector types that live across calls end up in scratch)
+template <int NA, int B0>
+__device__ __forceinline__ void q_load(float2 (&vn)[NA], int u, int D, const float2 *__restrict__ Mg) {
+    const int tj = threadIdx.x & 15;
+#pragma unroll
+    for (int b = B0; b < NA; ++b) {
+        const int j = 16 * b + tj;
+        vn[b] = (j < D && u >= 0) ? Mg[(int64_t)(u < 0 ? 0 : u) * D + j] : make_float2(0.f, 0.f);
+    }
+}
+
+// P <- P (I - conj(tau) v v^H) for the reflector with unit entry u, 16*A0 <= u < 16*(A0+1).  `vc`
+// holds reflector u on entry and reflector u - 1 on exit (its loads fly during this step).
 template <int NA, int A0>
 __device__ __forceinline__ void q_step(float2 (&m)[NA][NA], const TrShared<NA> &sh, int u, int D,
-                                       const float2 *__restrict__ Mg) {
-    const int tj = threadIdx.x & 15;
+                                       const float2 *__restrict__ Mg, float2 (&vcs)[NA]) {
+    constexpr int AP = A0 > 0 ? A0 - 1 : 0;
+    float2 vn[NA];
+    q_load<NA, AP>(vn, u - 1, D, Mg);
     const float2 tau = sh.taus[u];
-    if (tau.x == 0.f && tau.y == 0.f) return;
-    v2 vc[NA], vj[NA];
+    if (!(tau.x == 0.f && tau.y == 0.f)) {
+        v2 vc[NA], vj[NA], y[NA];
 #pragma unroll
-    for (int b = A0; b < NA; ++b) {
-        const int j = 16 * b + tj;
-        vc[b] = (j < D) ? tov2(Mg[(int64_t)u * D + j]) : v2{0.f, 0.f};
-        vj[b] = rot(vc[b]);
+        for (int b = A0; b < NA; ++b) {
+            vc[b] = tov2(vcs[b]);
+            vj[b] = rot(vc[b]);
+        }
+#pragma unroll
+        for (int a = A0; a < NA; ++a) {
+            v2 acc = {0.f, 0.f};
+#pragma unroll
+            for (int b = A0; b < NA; ++b) acc = pk_cmac(acc, tov2(m[a][b]), vc[b], vj[b]);
+            y[a] = acc;
+        }
+        row16_sum_all<NA, A0>(y);
+        const v2 nct = v2{-tau.x, tau.y}, nctj = rot(nct);   // -conj(tau)
+#pragma unroll
+        for (int a = A0; a < NA; ++a) {
+            const v2 nty = pk_cmac(v2{0.f, 0.f}, y[a], nct, nctj), ntyj = rotc(nty);
+#pragma unroll
+            for (int b = A0; b < NA; ++b) m[a][b] = tof2(pk_cmacc(tov2(m[a][b]), nty, ntyj, vc[b]));   // -= conj(tau) y conj(v_b)
+        }
     }
-    const float2 ctau = make_float2(tau.x, -tau.y);
 #pragma unroll
-    for (int a = A0; a < NA; ++a) {
-        v2 y = {0.f, 0.f};
-#pragma unroll
-        for (int b = A0; b < NA; ++b) y = pk_cmac(y, tov2(m[a][b]), vc[b], vj[b]);
-        y.x = row16_sum(y.x);
-        y.y = row16_sum(y.y);
-        const float2 ty = cmul(ctau, tof2(y));
-        const v2 nty = v2{-ty.x, -ty.y}, ntyj = rotc(nty);
-#pragma unroll
-        for (int b = A0; b < NA; ++b) m[a][b] = tof2(pk_cmacc(tov2(m[a][b]), nty, ntyj, vc[b]));   // -= conj(tau) y conj(v_b)
-    }
+    for (int b = AP; b < NA; ++b) vcs[b] = vn[b];
 }
 
 template <int NA, int A0>
@@ -210,10 +280,10 @@ struct TrPhases {
         if constexpr (A0 + 1 < NA) TrPhases<NA, A0 + 1>::forward(m, sh, D, corner, ag, Mg, dcol, ecol);
     }
     static __device__ __forceinline__ void backward(float2 (&m)[NA][NA], const TrShared<NA> &sh, int D,
-                                                    const float2 *Mg) {
-        if constexpr (A0 + 1 < NA) TrPhases<NA, A0 + 1>::backward(m, sh, D, Mg);
+                                                    const float2 *Mg, float2 (&vc)[NA]) {
+        if constexpr (A0 + 1 < NA) TrPhases<NA, A0 + 1>::backward(m, sh, D, Mg, vc);
         const int hi = min(16 * (A0 + 1), D);
-        for (int u = hi - 1; u >= 16 * A0; --u) q_step<NA, A0>(m, sh, u, D, Mg);
+        for (int u = hi - 1; u >= 16 * A0; --u) q_step<NA, A0>(m, sh, u, D, Mg, vc);
     }
 };
 
@@ -245,16 +315,15 @@ __global__ __launch_bounds__(TR_THREADS, 2) void tridiag_reg_kernel(int D, float
 
     // ---------------- tridiagonalisation: reflector u has its unit entry at index u ----------
     TrPhases<NA, 0>::forward(m, sh, D, corner, ag, Mg, dcol, ecol);
-    // last diagonal entry d[D] = Re M[D-1][D-1]
+    // last diagonal entry d[D] = Re M[D-1][D-1] (select chain: a run-time index would push m[][] to scratch)
     {
         const int k = D - 1, ka = k >> 4;
-        if (ti == (k & 15) && tj == (k & 15)) {
+        float dl = 0.f;
 #pragma unroll
-            for (int a = 0; a < NA; ++a)
-                if (a == ka) {
-                    dcol[D] = m[a][a].x;
-                    ecol[D] = 0.f;
-                }
+        for (int a = 0; a < NA; ++a) dl = (a == ka) ? m[a][a].x : dl;
+        if (ti == (k & 15) && tj == (k & 15)) {
+            dcol[D] = dl;
+            ecol[D] = 0.f;
         }
     }
     __syncthreads();   // reflector rows in Mg and taus[] complete
@@ -264,7 +333,9 @@ __global__ __launch_bounds__(TR_THREADS, 2) void tridiag_reg_kernel(int D, float
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < NA; ++b) m[a][b] = make_float2((a == b && ti == tj) ? 1.f : 0.f, 0.f);
-    TrPhases<NA, 0>::backward(m, sh, D, Mg);
+    float2 vc[NA];
+    q_load<NA, 0>(vc, D - 1, D, Mg);
+    TrPhases<NA, 0>::backward(m, sh, D, Mg, vc);
     // ---------------- QT[c][rho] = Q[rho][c] = conj(P[c][rho]) ---------------------------------
     float *q = QV + bm * ((int64_t)n * 2 * D);
 #pragma unroll
