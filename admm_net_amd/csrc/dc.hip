@@ -31,10 +31,11 @@ struct DcShared {
     int bnd[2][DC_MAXLEAF + 2];
     int kk[DC_MAXLEAF];      // non-deflated count per merge
     int nrot[DC_MAXLEAF];
+    int mx[DC_MAXLEAF][2];   // max |d|, max |z| of a merge as float bit patterns (non-negative: integer order)
     int fail;
 };
 
-__global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__restrict__ dT,
+__global__ __launch_bounds__(DC_THREADS, 5) void dc_kernel(int n, const float *__restrict__ dT,
                                                         const float *__restrict__ eT, float *__restrict__ Wbuf,
                                                         float *__restrict__ wout, float *__restrict__ w0out,
                                                         int *__restrict__ logn, int32_t *__restrict__ status,
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
         sh.bnd[0][nleaf] = n;
         sh.fail = 0;
     }
+    for (int i = tid; i < 2 * DC_MAXLEAF; i += DC_THREADS) (&sh.mx[0][0])[i] = 0;
     for (int i = tid; i < n; i += DC_THREADS) {
         lam[i] = dg[i];
         e0[i] = (i < n - 1) ? eg[i] : 0.f;
@@ -179,6 +181,8 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
                 perm[a + r] = i;
                 ds[a + r] = v;
                 zs[a + r] = z;
+                atomicMax(&sh.mx[team][0], __float_as_int(fabsf(v)));
+                atomicMax(&sh.mx[team][1], __float_as_int(fabsf(z)));
             }
         }
         __syncthreads();
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
         // P2: deflation scan (one thread per merge)
         if (act && tl == 0) {
             int k = 0, nr = 0;
-            deflate_scan(nn, rho, ds + a, zs + a, dl + a, zl + a, src + a, rot + a, k, nr);
+            deflate_scan_tol(nn, rho, __int_as_float(sh.mx[team][0]), __int_as_float(sh.mx[team][1]), ds + a, zs + a,
+                             dl + a, zl + a, src + a, rot + a, k, nr);
             sh.kk[team] = k;
             sh.nrot[team] = nr;
             for (int p = k; p < nn; ++p) vals[a + p] = dl[a + p];
@@ -196,15 +201,36 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
         const int k = act ? sh.kk[team] : 0;
         // P3: deflation rotations on the source columns (thread-private rows i) + secular roots
         if (act) {
+            // A chain of rotations (pa, pb) hands column pb on as the next pa: each thread keeps its
+            // rows of that running column in a register, so the chain never round-trips through memory;
+            // the other operand of every rotation is a column no earlier rotation touched, loaded
+            // four rotations ahead.
             const int nr = sh.nrot[team];
-            for (int r = 0; r < nr; ++r) {
-                const DcRot rr = rot[a + r];
-                float *x = Ws + (int64_t)(a + perm[a + rr.pa]) * n + a;
-                float *y = Ws + (int64_t)(a + perm[a + rr.pb]) * n + a;
-                for (int i = tl; i < nn; i += ts) {
-                    const float xi = x[i], yi = y[i];
-                    x[i] = rr.c * xi + rr.s * yi;
-                    y[i] = rr.c * yi - rr.s * xi;
+            for (int i = tl; i < nn; i += ts) {
+                float carry = 0.f;
+                int cpb = -1;
+                for (int r0 = 0; r0 < nr; r0 += 4) {
+                    DcRot rr[4];
+                    float xv[4], yv[4];
+                    int xo[4], yo[4];   // 32-bit element offsets: registers are what bounds the occupancy here
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        rr[q] = rot[a + min(r0 + q, nr - 1)];
+                        xo[q] = (a + perm[a + rr[q].pa]) * n + a + i;
+                        yo[q] = (a + perm[a + rr[q].pb]) * n + a + i;
+                        xv[q] = Ws[xo[q]];
+                        yv[q] = Ws[yo[q]];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (r0 + q < nr) {
+                            const float xi = (rr[q].pa == cpb) ? carry : xv[q], yi = yv[q];
+                            Ws[xo[q]] = rr[q].c * xi + rr[q].s * yi;
+                            carry = rr[q].c * yi - rr[q].s * xi;
+                            Ws[yo[q]] = carry;
+                            cpb = rr[q].pb;
+                        }
+                    }
                 }
             }
             for (int j = tl; j < k; j += ts) {
@@ -286,19 +312,24 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
                     const bool jv = (j0 + r) < mk, iv = (i0 + r) < mnn;
                     f32x16 acc = {0};
                     const int jo = jv ? j0 + r : 0, io = iv ? i0 + r : 0;
-                    for (int k0 = 0; k0 < mk; k0 += 16) {   // 8 K-steps per trip: loads first, then the MFMAs
-                        float av[8], bv[8];
+                    // 8 K-steps per batch (the operands sit in L2, ~1 us away)
+                    auto ld1 = [&](int k0, int s8, float &av, float &bv) {
+                        const int kq = k0 + 2 * s8 + kh;
+                        const bool kv = kq < mk;
+                        const int kc = kv ? kq : 0;
+                        // A[j][kk] = U[kk][j]; B[kk][i] = WTsrc[col(kk)][i]
+                        const float a_ = U[(ma + kc) * n + ma + jo];
+                        const float b_ = Ws[(ma + cidx[ma + kc]) * n + ma + io];
+                        av = (kv && jv) ? a_ : 0.f;
+                        bv = (kv && iv) ? b_ : 0.f;
+                    };
+                    auto ld8 = [&](int k0, float (&av)[8], float (&bv)[8]) {
 #pragma unroll
-                        for (int s8 = 0; s8 < 8; ++s8) {
-                            const int kq = k0 + 2 * s8 + kh;
-                            const bool kv = kq < mk;
-                            const int kc = kv ? kq : 0;
-                            // A[j][kk] = U[kk][j]; B[kk][i] = WTsrc[col(kk)][i]
-                            const float a_ = U[(int64_t)(ma + kc) * n + ma + jo];
-                            const float b_ = Ws[(int64_t)(ma + cidx[ma + kc]) * n + ma + io];
-                            av[s8] = (kv && jv) ? a_ : 0.f;
-                            bv[s8] = (kv && iv) ? b_ : 0.f;
-                        }
+                        for (int s8 = 0; s8 < 8; ++s8) ld1(k0, s8, av[s8], bv[s8]);
+                    };
+                    for (int k0 = 0; k0 < mk; k0 += 16) {   // loads of a whole batch first, then its MFMAs
+                        float av[8], bv[8];
+                        ld8(k0, av, bv);
 #pragma unroll
                         for (int s8 = 0; s8 < 8; ++s8)
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s8], bv[s8], acc, 0, 0, 0);
@@ -316,6 +347,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_kernel(int n, const float *__re
         mark(7);
         // P7: commit eigenvalues and block boundaries
         for (int i = tid; i < n; i += DC_THREADS) lam[i] = lamn[i];
+        for (int i = tid; i < 2 * DC_MAXLEAF; i += DC_THREADS) (&sh.mx[0][0])[i] = 0;
         if (tid == 0) {
             int o = 0;
             for (int q = 0; q < nm; ++q) sh.bnd[cb ^ 1][o++] = bn[2 * q];

@@ -33,6 +33,33 @@ HD float fdiv_fast(float a, float b) {
 // (columns).  A team of `kstep` lanes may share one leaf: every lane runs the (cheap) scalar
 // recurrence on the shared d / e -- all lanes write identical values -- and owns the rows
 // k0, k0 + kstep, ... of Z.  (k0, kstep) = (0, 1) is the single-thread form.  Returns 0 / 1.
+// Plane rotation (r, sn, c) with r = hypot(f, g), sn = f / r, c = g / r.  Device: one v_rsq_f32 and a
+// first-order renormalisation of (sn, c) (keeps sn^2 + c^2 = 1 to rounding, which is what the
+// orthogonality of the accumulated Z needs) instead of an IEEE sqrt and two IEEE divisions on the
+// serial path; values outside the safe exponent range take the exact route.
+HD void plane_rot(float f, float g, float &r, float &sn, float &c) {
+    const float q = f * f + g * g;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (q > 1e-30f && q < 1e30f) {
+        const float ir = __builtin_amdgcn_rsqf(q);
+        const float s0 = f * ir, c0 = g * ir;
+        const float h = 0.5f * (1.0f - (s0 * s0 + c0 * c0));
+        sn = fmaf(h, s0, s0);
+        c = fmaf(h, c0, c0);
+        r = q * ir;
+        return;
+    }
+#endif
+    r = sqrtf(q);
+    if (r == 0.0f) {
+        sn = 0.f;
+        c = 1.f;
+        return;
+    }
+    sn = f / r;
+    c = g / r;
+}
+
 template <class FA, class ZA>
 HD int leaf_ql(int s, FA d, FA e, ZA Z, int k0 = 0, int kstep = 1) {
     for (int i = k0; i < s; i += kstep)
@@ -41,44 +68,53 @@ HD int leaf_ql(int s, FA d, FA e, ZA Z, int k0 = 0, int kstep = 1) {
     for (int l = 0; l < s; ++l) {
         int iter = 0, m;
         do {
-            for (m = l; m < s - 1; ++m) {
-                const float dd = fabsf(d[m]) + fabsf(d[m + 1]);
-                if (fabsf(e[m]) <= kEps32 * dd) break;
+            // smallest m >= l with a negligible e[m] (no early exit: the loads pipeline)
+            m = s - 1;
+            for (int q = s - 2; q >= l; --q) {
+                const float dd = fabsf(d[q]) + fabsf(d[q + 1]);
+                if (fabsf(e[q]) <= kEps32 * dd) m = q;
             }
             if (m != l) {
                 if (iter++ >= 60) return 1;
-                float g = (d[l + 1] - d[l]) / (2.0f * e[l]);
+                float g = fdiv_fast(d[l + 1] - d[l], 2.0f * e[l]);
                 float r = sqrtf(g * g + 1.0f);
-                g = d[m] - d[l] + e[l] / (g + sign_of(r, g));
+                g = d[m] - d[l] + fdiv_fast(e[l], g + sign_of(r, g));
                 float sn = 1.0f, c = 1.0f, p = 0.0f;
-                int i;
+                // every value the sweep reads is the one from before the sweep: fetch one step ahead
+                float d_up = d[m], e_i = e[m - 1], d_i = d[m - 1];
                 bool brk = false;
-                for (i = m - 1; i >= l; --i) {
-                    float f = sn * e[i];
-                    const float b = c * e[i];
-                    r = sqrtf(f * f + g * g);
+                for (int i = m - 1; i >= l; --i) {
+                    float e_n = 0.f, d_n = 0.f;
+                    if (i > l) {
+                        e_n = e[i - 1];
+                        d_n = d[i - 1];
+                    }
+                    const float f = sn * e_i;
+                    const float b = c * e_i;
+                    plane_rot(f, g, r, sn, c);
                     e[i + 1] = r;
                     if (r == 0.0f) {
-                        d[i + 1] -= p;
+                        d[i + 1] = d_up - p;
                         e[m] = 0.0f;
                         brk = true;
                         break;
                     }
-                    sn = f / r;
-                    c = g / r;
-                    g = d[i + 1] - p;
-                    r = (d[i] - g) * sn + 2.0f * c * b;
+                    g = d_up - p;
+                    r = (d_i - g) * sn + 2.0f * c * b;
                     p = sn * r;
                     d[i + 1] = g + p;
                     g = c * r - b;
                     for (int k = k0; k < s; k += kstep) {
-                        f = Z(k, i + 1);
-                        Z(k, i + 1) = sn * Z(k, i) + c * f;
-                        Z(k, i) = c * Z(k, i) - sn * f;
+                        const float zf = Z(k, i + 1);
+                        Z(k, i + 1) = sn * Z(k, i) + c * zf;
+                        Z(k, i) = c * Z(k, i) - sn * zf;
                     }
+                    d_up = d_i;
+                    e_i = e_n;
+                    d_i = d_n;
                 }
                 if (brk) continue;
-                d[l] -= p;
+                d[l] = d_up - p;
                 e[l] = g;
                 e[m] = 0.0f;
             }
@@ -101,13 +137,12 @@ struct DcRot {
     float c, s;
 };
 
+// The scan is a serial chain over (pj, d_pj, z_pj): that state is carried in registers and the
+// next (d, z) pair is fetched one step ahead, so the chain never waits on the LDS.  `dzmax` =
+// max(max |ds|, max |zs|) is supplied by the caller (team reduction on the device).
 template <class FA, class IA, class RA>
-HD void deflate_scan(int nn, float rho, FA ds, FA zs, FA dl, FA zl, IA src, RA rot, int &k_out, int &nrot_out) {
-    float dmax = 0.f, zmax = 0.f;
-    for (int i = 0; i < nn; ++i) {
-        dmax = fmaxf(dmax, fabsf(ds[i]));
-        zmax = fmaxf(zmax, fabsf(zs[i]));
-    }
+HD void deflate_scan_tol(int nn, float rho, float dmax, float zmax, FA ds, FA zs, FA dl, FA zl, IA src, RA rot,
+                         int &k_out, int &nrot_out) {
     const float tol = 8.0f * kEps32 * fmaxf(dmax, zmax);
     int k = 0, k2 = nn, nrot = 0;
     if (rho * zmax <= tol) {   // the rank-one term is negligible: everything deflates
@@ -121,50 +156,59 @@ HD void deflate_scan(int nn, float rho, FA ds, FA zs, FA dl, FA zl, IA src, RA r
         return;
     }
     int pj = -1;
+    float dpj = 0.f, zpj = 0.f;
+    float dn = ds[0], zn = zs[0];
     for (int j = 0; j < nn; ++j) {
-        if (rho * fabsf(zs[j]) <= tol) {   // type 1: tiny z component
+        const float dj = dn, zj = zn;
+        if (j + 1 < nn) {
+            dn = ds[j + 1];
+            zn = zs[j + 1];
+        }
+        if (rho * fabsf(zj) <= tol) {   // type 1: tiny z component
             --k2;
-            dl[k2] = ds[j];
+            dl[k2] = dj;
             src[k2] = j;
             continue;
         }
         if (pj < 0) {
             pj = j;
+            dpj = dj;
+            zpj = zj;
             continue;
         }
         // type 2: two (nearly) equal poles -> rotate z_pj into z_j
-        float s = zs[pj], c = zs[j];
+        float s = zpj, c = zj;
         const float tau = sqrtf(c * c + s * s);
-        const float t = ds[j] - ds[pj];
-        c /= tau;
-        s = -s / tau;
+        const float t = dj - dpj;
+        const float itau = recip_nr(tau);
+        c *= itau;
+        s = -s * itau;
         if (fabsf(t * c * s) <= tol) {
-            zs[j] = tau;
-            zs[pj] = 0.f;
             DcRot r;
             r.pa = pj;
             r.pb = j;
             r.c = c;
             r.s = s;
             rot[nrot++] = r;
-            const float tt = ds[pj] * c * c + ds[j] * s * s;
-            ds[j] = ds[pj] * s * s + ds[j] * c * c;
-            ds[pj] = tt;
             --k2;
-            dl[k2] = ds[pj];
+            dl[k2] = dpj * c * c + dj * s * s;
             src[k2] = pj;
+            dpj = dpj * s * s + dj * c * c;
+            zpj = tau;
             pj = j;
         } else {
-            dl[k] = ds[pj];
-            zl[k] = zs[pj];
+            dl[k] = dpj;
+            zl[k] = zpj;
             src[k] = pj;
             ++k;
             pj = j;
+            dpj = dj;
+            zpj = zj;
         }
     }
     if (pj >= 0) {
-        dl[k] = ds[pj];
-        zl[k] = zs[pj];
+        dl[k] = dpj;
+        zl[k] = zpj;
         src[k] = pj;
         ++k;
     }
@@ -172,113 +216,131 @@ HD void deflate_scan(int nn, float rho, FA ds, FA zs, FA dl, FA zl, IA src, RA r
     nrot_out = nrot;
 }
 
+template <class FA, class IA, class RA>
+HD void deflate_scan(int nn, float rho, FA ds, FA zs, FA dl, FA zl, IA src, RA rot, int &k_out, int &nrot_out) {
+    float dmax = 0.f, zmax = 0.f;
+    for (int i = 0; i < nn; ++i) {
+        dmax = fmaxf(dmax, fabsf(ds[i]));
+        zmax = fmaxf(zmax, fabsf(zs[i]));
+    }
+    deflate_scan_tol(nn, rho, dmax, zmax, ds, zs, dl, zl, src, rot, k_out, nrot_out);
+}
+
 // ---------------------------------------------------------------------------------------------
-// Secular equation  f(lam) = 1 + rho * sum_i z_i^2 / (d_i - lam) = 0,  root j of k (0-based),
+// Secular equation  w(lam) = 1/rho + sum_i z_i^2 / (d_i - lam) = 0,  root j of k (0-based),
 // d ascending and distinct, rho > 0, ||z|| = 1.  Root j lies in (d_j, d_{j+1}) (last: (d_{k-1},
 // d_{k-1} + rho)).  Returns the origin pole `org` and tau with lam_j = d_org + tau; differences
 // d_i - lam_j are then formed as (d_i - d_org) - tau, which keeps them accurate relative to
-// themselves (the property LAPACK slaed4 is built around).  Bracketing Illinois iteration on
-// the pole-free transform h(t) = f * (t - pl)(pr - t).
+// themselves (the property LAPACK slaed4 is built around).
+//
+// Iteration: R.-C. Li's "middle way" (the scheme inside slaed4): split w = 1/rho + psi + phi at the
+// root's interval, model psi by s + p / (d_lo - lam) and phi by S + P / (d_hi - lam) matching value
+// and slope at the current point, and solve the resulting quadratic for the step.  Quadratic
+// convergence, no stagnating bracket end; a bracket [lo, hi] (w(lo) < 0 < w(hi)) is kept anyway and a
+// step that leaves it is replaced by bisection.  Stop when |w| is below the rounding noise of its
+// own evaluation (slaed4's criterion).  One evaluation = one pass over the k poles.
+struct SecEval {
+    float w, dpsi, dphi, err;
+};
+
 template <class FA>
-HD void secular_root(int k, int j, float rho, FA d, FA z, int &org_out, float &tau_out) {
+HD SecEval secular_eval(int k, int jsplit, float rhoinv, float dorg, float t, FA d, FA z) {
+    // psi: poles 0..jsplit, phi: the rest
+    float sum = 0.f, asum = 0.f, dall = 0.f, dps = 0.f;
+    for (int i = 0; i < k; ++i) {
+        const float del = (d[i] - dorg) - t;
+        const float r = fdiv_fast(1.0f, del);
+        const float term = z[i] * z[i] * r;
+        const float dterm = term * r;
+        sum += term;
+        asum += fabsf(term);
+        dall += dterm;
+        dps += (i <= jsplit) ? dterm : 0.f;
+    }
+    SecEval e;
+    e.w = rhoinv + sum;
+    e.dpsi = dps;
+    e.dphi = dall - dps;
+    e.err = 8.0f * asum + rhoinv + fabsf(t) * dall;
+    return e;
+}
+
+template <class FA>
+HD void secular_root(int k, int j, float rho, FA d, FA z, int &org_out, float &tau_out, int *nit = nullptr) {
+    if (nit) *nit = 0;
     if (k == 1) {
         org_out = 0;
         tau_out = rho * z[0] * z[0];
         return;
     }
+    const float rhoinv = 1.0f / rho;
     const bool last = (j == k - 1);
-    // evaluate f at lam = d_org + t, also returns it for the transform
-    auto feval = [&](int org, float t) -> float {
-        float acc = 0.f;
-        const float dorg = d[org];
-        for (int i = 0; i < k; ++i) {
-            const float del = (d[i] - dorg) - t;
-            acc = fmaf(z[i] * z[i], fdiv_fast(1.0f, del), acc);
-        }
-        return 1.0f + rho * acc;
-    };
+    // the two poles the rational model keeps exact, and the psi / phi split
+    const int plo = last ? k - 2 : j, phi_ = last ? k - 1 : j + 1;
+    const int jsplit = plo;
     int org;
-    float lo, hi;   // bracket in tau, f(lo) < 0 < f(hi) once inside
+    float lo, hi, t;
+    SecEval e;
     if (last) {
         org = k - 1;
         lo = 0.f;
-        hi = rho;   // f(d_{k-1} + rho ||z||^2) >= 0
-        if (feval(org, hi) <= 0.f) {   // numerical corner: root at / beyond the upper bound
-            org_out = org;
-            tau_out = hi;
-            return;
-        }
+        hi = rho;
+        t = 0.5f * rho;
+        e = secular_eval(k, jsplit, rhoinv, d[org], t, d, z);
     } else {
         const float gap = d[j + 1] - d[j];
         const float half = 0.5f * gap;
-        const float fm = feval(j, half);
-        if (fm >= 0.f) {
+        e = secular_eval(k, jsplit, rhoinv, d[j], half, d, z);
+        if (e.w >= 0.f) {   // root in the left half: measure from d_j
             org = j;
             lo = 0.f;
             hi = half;
-        } else {
+            t = half;
+        } else {            // right half: measure from d_{j+1}
             org = j + 1;
             lo = -half;
             hi = 0.f;
+            t = -half;
         }
     }
-    // poles adjacent to the bracket, relative to the origin
-    const float pl = (org == j || last) ? 0.f : (d[j] - d[org]);           // left pole offset
-    const float pr = last ? 2.0f * rho + 0.f : ((org == j) ? (d[j + 1] - d[org]) : 0.f);   // right pole offset
-    auto heval = [&](float t) -> float {
-        const float f = feval(org, t);
-        return last ? f * (t - pl) : f * (t - pl) * (pr - t);
-    };
-    // bracket ends: at t = pl (resp. pr) h has a finite limit of known sign (-, +): use the limits
-    // h(pl+) = -rho z_j^2 (pr - pl) < 0,  h(pr-) = +rho z_{j+1}^2 (pr - pl) > 0; interior ends evaluated.
-    float a = lo, b = hi, ha, hb;
-    if (last) {
-        ha = -rho * z[k - 1] * z[k - 1];
-        hb = heval(b);
-    } else if (org == j) {
-        ha = -rho * z[j] * z[j] * (pr - pl);
-        hb = heval(b);
-    } else {
-        ha = heval(a);
-        hb = rho * z[j + 1] * z[j + 1] * (pr - pl);
-    }
-    float t = 0.5f * (a + b);
-    if (!(ha < 0.f && hb > 0.f)) {   // degenerate bracket (ha == 0 or hb == 0 numerically)
-        org_out = org;
-        tau_out = (ha >= 0.f) ? a : b;
-        if (tau_out == 0.f) tau_out = (org == j || last) ? 1e-30f : -1e-30f;
-        return;
-    }
-    int side = 0;
-    for (int it = 0; it < 80; ++it) {
-        // Illinois step, kept strictly inside the bracket; fall back to bisection when it stalls
-        float tn = b - hb * (b - a) / (hb - ha);
-        if (!(tn > a && tn < b)) tn = 0.5f * (a + b);
-        if (tn == a || tn == b) {
-            t = tn;
-            break;
-        }
-        const float hn = heval(tn);
-        t = tn;
-        if (hn == 0.f) break;
-        if (hn < 0.f) {
-            a = tn;
-            ha = hn;
-            if (side == -1) hb *= 0.5f;
-            side = -1;
+    const float dorg = d[org];
+    const float plo_off = d[plo] - dorg, phi_off = d[phi_] - dorg;
+    for (int it = 0; it < 40; ++it) {
+        if (nit) *nit = it + 1;
+        if (fabsf(e.w) <= kEps32 * e.err) break;
+        if (e.w < 0.f) lo = t; else hi = t;
+        const float d1 = plo_off - t, d2 = phi_off - t;   // distances to the two modelled poles
+        const float dw = e.dpsi + e.dphi;
+        float c = e.w - d1 * e.dpsi - d2 * e.dphi;
+        const float aa = (d1 + d2) * e.w - d1 * d2 * dw;
+        const float bb = d1 * d2 * e.w;
+        float eta;
+        if (last) {
+            if (c < 0.f) c = -c;
+            if (c == 0.f) {
+                eta = hi - t;
+            } else {
+                const float disc = sqrtf(fabsf(aa * aa - 4.0f * bb * c));
+                eta = (aa >= 0.f) ? fdiv_fast(aa + disc, 2.0f * c) : fdiv_fast(2.0f * bb, aa - disc);
+            }
         } else {
-            b = tn;
-            hb = hn;
-            if (side == 1) ha *= 0.5f;
-            side = 1;
+            if (c == 0.f) {
+                eta = (aa != 0.f) ? fdiv_fast(bb, aa) : 0.f;
+            } else {
+                const float disc = sqrtf(fabsf(aa * aa - 4.0f * bb * c));
+                eta = (aa <= 0.f) ? fdiv_fast(aa - disc, 2.0f * c) : fdiv_fast(2.0f * bb, aa + disc);
+            }
         }
-        // converged when the bracket is within a couple of ulps of |t|
-        if ((b - a) <= 4.0f * kEps32 * fmaxf(fabsf(a), fabsf(b))) {
-            t = 0.5f * (a + b);
-            break;
-        }
+        if (!(e.w * eta < 0.f)) eta = -fdiv_fast(e.w, dw);   // wrong direction (or NaN): Newton step
+        float tn = t + eta;
+        if (!(tn > lo && tn < hi)) tn = 0.5f * (lo + hi);
+        if (tn == t || tn == lo || tn == hi) break;           // bracket exhausted at this precision
+        t = tn;
+        e = secular_eval(k, jsplit, rhoinv, dorg, t, d, z);
     }
-    if (t == 0.f) t = (org == j || last) ? a + 0.5f * (b - a) : b - 0.5f * (b - a);
+    // never return a pole itself (the Loewner products divide by these differences)
+    if (t == 0.f) t = (lo == 0.f) ? 0.5f * hi : 0.5f * lo;
+    if (t == 0.f) t = (org == j || last) ? 1e-30f : -1e-30f;
     org_out = org;
     tau_out = t;
 }
@@ -297,7 +359,7 @@ HD float lowner_zhat(int k, int i, FA d, FA z, IA org, FA tau) {
     float w = dc_delta(d, org, tau, i, i);   // d_i - lam_i
     for (int j = 0; j < k; ++j) {
         if (j == i) continue;
-        w *= dc_delta(d, org, tau, i, j) / (d[i] - d[j]);
+        w *= fdiv_fast(dc_delta(d, org, tau, i, j), d[i] - d[j]);
     }
     const float r = sqrtf(fabsf(w));
     return z[i] >= 0.f ? r : -r;

@@ -19,7 +19,7 @@ struct Ctx {
     int n;
     std::vector<float> lam, WA, WB;   // WT layout: W?[j * n + i] = W[i][j]
     std::vector<float> e0;            // original off-diagonals
-    int stat_defl = 0, stat_k = 0, stat_iter = 0;
+    int stat_defl = 0, stat_k = 0, stat_iter = 0, stat_itmax = 0;
 };
 
 // merge blocks [a, b) and [b, c); reads `src`, writes `dst` (both WT layout), updates lam
@@ -71,7 +71,10 @@ int merge(Ctx &cx, int a, int b, int c, const std::vector<float> &srcW, std::vec
     std::vector<float> tau(k), zh(k), U((size_t)k * k), vals(nn);
     std::vector<int> org(k);
     for (int j = 0; j < k; ++j) {
-        secular_root(k, j, rho, dl.data(), zl.data(), org[j], tau[j]);
+        int nit = 0;
+        secular_root(k, j, rho, dl.data(), zl.data(), org[j], tau[j], &nit);
+        cx.stat_iter += nit;
+        cx.stat_itmax = std::max(cx.stat_itmax, nit);
         vals[j] = dl[org[j]] + tau[j];
     }
     for (int i = 0; i < k; ++i) zh[i] = lowner_zhat(k, i, dl.data(), zl.data(), org.data(), tau.data());
@@ -116,7 +119,7 @@ int merge(Ctx &cx, int a, int b, int c, const std::vector<float> &srcW, std::vec
 extern "C" {
 
 // d[n], e[n] (e[i] couples i, i+1) -> lam[n] ascending, WT[n*n] with WT[j*n+i] = W[i][j].
-// stats[3]: deflated count, secular roots solved, reserved.  Returns 0 or the leaf status.
+// stats[4]: deflated count, secular roots solved, secular iterations (sum, max).  Returns 0 or the leaf status.
 int dc_solve(int n, const float *d_in, const float *e_in, float *lam_out, float *WT_out, int *stats) {
     Ctx cx;
     cx.n = n;
@@ -177,7 +180,8 @@ int dc_solve(int n, const float *d_in, const float *e_in, float *lam_out, float 
     if (stats) {
         stats[0] = cx.stat_defl;
         stats[1] = cx.stat_k;
-        stats[2] = 0;
+        stats[2] = cx.stat_iter;
+        stats[3] = cx.stat_itmax;
     }
     return 0;
 }

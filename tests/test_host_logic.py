@@ -269,3 +269,69 @@ def test_host_model_clustered_spectrum(host_model):
     A64 = Ah.astype(np.complex128)
     rec = (V * w) @ V.conj().T
     assert np.abs(rec - A64).max() < 2e-5 * np.abs(A64).max()
+
+
+# ---------------------------------------------------------------- host model of the divide & conquer eigensolver
+@pytest.fixture(scope="module")
+def dc_model():
+    so = os.path.join(ROOT, "tests", "host_model", "libdc_model.so")
+    src = os.path.join(ROOT, "tests", "host_model", "dc_model.cpp")
+    cores = [os.path.join(ROOT, "admm_net_amd", "csrc", f) for f in ("dc_core.h", "eig_core.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + cores):
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-I", os.path.dirname(cores[0]), src, "-o", so])
+    return ctypes.CDLL(so)
+
+
+def _dc_solve(lib, d, e):
+    n = len(d)
+    lam = np.zeros(n, np.float32); WT = np.zeros((n, n), np.float32); st = (ctypes.c_int * 4)()
+    rc = lib.dc_solve(n, d.ctypes.data_as(ctypes.c_void_p), e.ctypes.data_as(ctypes.c_void_p),
+                      lam.ctypes.data_as(ctypes.c_void_p), WT.ctypes.data_as(ctypes.c_void_p), st)
+    return rc, lam, WT.T.copy(), list(st)
+
+
+def _tridiagonal_cases():
+    import scipy.linalg as sl
+    rng = np.random.default_rng(11)
+
+    def tri(A):
+        H = sl.hessenberg(A)
+        d = np.real(np.diag(H)).astype(np.float32)
+        return d, np.append(np.abs(np.diag(H, -1)), 0).astype(np.float32)
+
+    def herm(n):
+        X = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        return (X + X.conj().T) / 2
+
+    def layer_like(n, r, c, sd):   # scalar * I + small diagonal + low rank: what the G-layer sees
+        U = rng.standard_normal((n, r)) + 1j * rng.standard_normal((n, r))
+        return c * np.eye(n) + np.diag(sd * rng.standard_normal(n)) + U @ np.diag(3 * rng.standard_normal(r)) @ U.conj().T
+
+    cases = {"random2": tri(herm(2)), "random9": tri(herm(9)), "random17": tri(herm(17)), "random64": tri(herm(64)),
+             "random129": tri(herm(129)), "random257": tri(herm(257)),
+             "clustered129": tri(layer_like(129, 5, 0.003, 1e-4)), "clustered257": tri(layer_like(257, 8, 0.01, 1e-5)),
+             "identity40": (np.ones(40, np.float32), np.zeros(40, np.float32))}
+    n = 21   # Wilkinson W21+: pairs of eigenvalues agreeing to working precision
+    e = np.ones(n, np.float32); e[-1] = 0
+    cases["wilkinson21"] = (np.abs(np.arange(n) - 10).astype(np.float32), e)
+    e = np.ones(63, np.float32); e[20] = e[41] = 1e-6; e[-1] = 0   # three copies glued by tiny couplings
+    cases["glued63"] = (np.tile(np.abs(np.arange(21) - 10), 3).astype(np.float32), e)
+    return cases
+
+
+@pytest.mark.parametrize("name", ["random2", "random9", "random17", "random64", "random129", "random257",
+                                  "clustered129", "clustered257", "identity40", "wilkinson21", "glued63"])
+def test_dc_model(dc_model, name):
+    """Divide & conquer cores (dc_core.h) run sequentially on the CPU: residual, orthogonality,
+    eigenvalues vs LAPACK in float64, and the secular solver's iteration count."""
+    d, e = _tridiagonal_cases()[name]
+    n = len(d)
+    rc, lam, W, st = _dc_solve(dc_model, d, e)
+    assert rc == 0
+    T = np.diag(d.astype(np.float64)) + np.diag(e[:-1].astype(np.float64), 1) + np.diag(e[:-1].astype(np.float64), -1)
+    scale = max(np.abs(T).max(), 1e-30)
+    assert np.all(np.diff(lam) >= 0)
+    assert np.abs(T @ W - W * lam).max() < 4e-6 * scale
+    assert np.abs(W.T @ W - np.eye(n)).max() < 6e-6
+    assert np.abs(lam - np.linalg.eigvalsh(T)).max() < 2e-6 * scale
+    assert st[3] <= 25   # middle-way iteration: a handful of passes per root, bisection fallbacks are rare
