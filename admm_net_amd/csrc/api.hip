@@ -150,12 +150,20 @@ int carve_workspace(const admmnet_cfg *cfg, int64_t B, void *base, int64_t bytes
     return ADMMNET_OK;
 }
 
-static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st) {
+// The G-layer can take V = Q W inside its rebuild kernel (backrebuild.hip, D <= 128, D&C path):
+// then the eigen-solve stops at (Q, W) and V never goes through memory.  ADMMNET_FUSE_BACK=0 keeps
+// the separate kernels (tuning / debugging aid).
+static bool fuse_back(int D, const Ws &ws) {
+    static const bool on = !(getenv("ADMMNET_FUSE_BACK") && atoi(getenv("ADMMNET_FUSE_BACK")) == 0);
+    return on && ws.Wdc && back_rebuild_supported(D);
+}
+
+static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool with_v = true) {
     int rc;
     if ((rc = launch_tridiag(D, nb, ws, st))) return rc;
     if (ws.Wdc) {   // divide & conquer + V = Q W on the matrix cores
         if ((rc = launch_dc(D + 1, nb, ws, status, st))) return rc;
-        return launch_vgemm(D, nb, ws, st);
+        return with_v ? launch_vgemm(D, nb, ws, st) : ADMMNET_OK;
     }
     if ((rc = launch_tql(D + 1, nb, ws, status, st))) return rc;
     return launch_rotapply(D, nb, ws, st);
@@ -339,9 +347,10 @@ int admmnet_layer_front(const admmnet_cfg *cfg, const float *W, int32_t k, const
     for (int64_t b0 = 0; b0 < B; b0 += ws.chunk) {
         const int64_t nb = (B - b0 < ws.chunk) ? (B - b0) : ws.chunk;
         if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, ws, false, st))) return rc;
-        if ((rc = eig_chunk(D, nb, ws, status, st))) return rc;
-        if ((rc = launch_rebuild(D, nb, lw, ws.phi[cur] + b0 * D, ws.h[cur] + b0 * D, ws.G + b0 * n * n,
-                                 ws.rn + b0, nullptr, ws, st)))
+        const bool fused = fuse_back(D, ws);
+        if ((rc = eig_chunk(D, nb, ws, status, st, !fused))) return rc;
+        if ((rc = (fused ? launch_back_rebuild : launch_rebuild)(D, nb, lw, ws.phi[cur] + b0 * D, ws.h[cur] + b0 * D,
+                                                                 ws.G + b0 * n * n, ws.rn + b0, nullptr, ws, st)))
             return rc;
     }
     return launch_rn_sum(B, ws.rn, sum_out ? sum_out : ws.sum, st);
@@ -430,9 +439,11 @@ int admmnet_glayer_f32(const admmnet_cfg *cfg, const float *lw, const void *phi,
         const float2 *ph = (const float2 *)phi + b0 * D;
         const float2 *Zc = Z ? (const float2 *)Z + b0 * n * n : nullptr;
         if ((rc = launch_build_block(D, nb, sc[S_CORNER_G], sc[S_INV_RHO_G], ph, h + b0 * D, Zc, ws, st))) return rc;
-        if ((rc = eig_chunk(D, nb, ws, status, st))) return rc;
-        if ((rc = launch_rebuild(D, nb, lw, ph, h + b0 * D, (float2 *)G_out + b0 * n * n,
-                                 rn_out ? rn_out + b0 : rn_tmp + b0, w_out ? w_out + b0 * n : nullptr, ws, st)))
+        const bool fused = fuse_back(D, ws);
+        if ((rc = eig_chunk(D, nb, ws, status, st, !fused))) return rc;
+        if ((rc = (fused ? launch_back_rebuild : launch_rebuild)(
+                 D, nb, lw, ph, h + b0 * D, (float2 *)G_out + b0 * n * n, rn_out ? rn_out + b0 : rn_tmp + b0,
+                 w_out ? w_out + b0 * n : nullptr, ws, st)))
             return rc;
     }
     return ADMMNET_OK;

@@ -125,6 +125,9 @@ int launch_rotapply(int D, int64_t nb, const Ws &ws, hipStream_t st);
 // rebuild.hip
 int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st);     // dc.hip
 int launch_vgemm(int D, int64_t nb, const Ws &ws, hipStream_t st);                       // dc.hip
+bool back_rebuild_supported(int D);                                                        // backrebuild.hip
+int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G,
+                        float *rn, float *w_out, const Ws &ws, hipStream_t st);           // backrebuild.hip
 bool use_dc();                                                                          // api.hip
 int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h,
                    float2 *G, float *rn, float *w_out, const Ws &ws, hipStream_t st);

@@ -26,6 +26,12 @@ constexpr int DC_THREADS = 256;
 constexpr int DC_LS = 8;          // leaf size (the last leaf absorbs the remainder)
 constexpr int DC_MAXLEAF = 33;    // n <= 8 * 33 + 7
 constexpr int DC_MAXLS = 2 * DC_LS;
+constexpr int DC_LDZ = DC_LS + 1;          // row pitch of a leaf's Z (odd: the team's row-per-lane accesses spread over banks)
+constexpr int DC_LDZ_LAST = DC_MAXLS + 1;  // the last leaf holds up to 2 * DC_LS - 1 rows
+
+__host__ __device__ constexpr size_t dc_leafz_floats(int nleaf) {
+    return (size_t)(nleaf - 1) * DC_LS * DC_LDZ + (size_t)DC_MAXLS * DC_LDZ_LAST;
+}
 
 struct DcShared {
     int bnd[2][DC_MAXLEAF + 2];
@@ -35,7 +41,8 @@ struct DcShared {
     int fail;
 };
 
-__global__ __launch_bounds__(DC_THREADS, 5) void dc_kernel(int n, const float *__restrict__ dT,
+template <int OCC>
+__global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float *__restrict__ dT,
                                                         const float *__restrict__ eT, float *__restrict__ Wbuf,
                                                         float *__restrict__ wout, float *__restrict__ w0out,
                                                         int *__restrict__ logn, int32_t *__restrict__ status,
@@ -62,6 +69,7 @@ __global__ __launch_bounds__(DC_THREADS, 5) void dc_kernel(int n, const float *_
     float *zv = e0 + NP;
     float *ds = zv + NP;
     float *zs = ds + NP;
+    float *un = zs;            // (after the deflation scan) 1 / ||u_j|| of the merge's rank-one eigenvectors
     float *dl = zs + NP;
     float *zl = dl + NP;
     float *tau = zl + NP;
@@ -74,8 +82,8 @@ __global__ __launch_bounds__(DC_THREADS, 5) void dc_kernel(int n, const float *_
     int *rnk = org + NP;
     int *cidx = rnk + NP;                                      // source column (block-local) of merged position p
     DcRot *rot = reinterpret_cast<DcRot *>(cidx + NP);         // [NP]
-    float *leafZ = reinterpret_cast<float *>(rot + NP);         // [nleaf][DC_MAXLS * DC_MAXLS]
-    float *leafD = leafZ + (size_t)max(1, n / DC_LS) * DC_MAXLS * DC_MAXLS;   // [nleaf][2 * DC_MAXLS]
+    float *leafZ = reinterpret_cast<float *>(rot + NP);         // [nleaf - 1][DC_LS * DC_LDZ] + [DC_MAXLS * DC_LDZ_LAST]
+    float *leafD = leafZ + dc_leafz_floats(max(1, n / DC_LS));   // [nleaf][2 * DC_MAXLS]
 
     float *WA = Wbuf + bm * (int64_t)3 * n * n;
     float *WB = WA + (int64_t)n * n;
@@ -114,12 +122,13 @@ __global__ __launch_bounds__(DC_THREADS, 5) void dc_kernel(int n, const float *_
         if (leaf < nleaf) {
             const int a = sh.bnd[0][leaf], s = sh.bnd[0][leaf + 1] - a;
             float *dd = leafD + (size_t)leaf * 2 * DC_MAXLS, *ee = dd + DC_MAXLS;
-            float *Z = leafZ + (size_t)leaf * DC_MAXLS * DC_MAXLS;
+            float *Z = leafZ + (size_t)leaf * DC_LS * DC_LDZ;
+            const int ldz = (leaf == nleaf - 1) ? DC_LDZ_LAST : DC_LDZ;
             for (int i = 0; i < s; ++i) {   // identical values from every lane of the team
                 dd[i] = lam[a + i];
                 ee[i] = (i < s - 1) ? e0[a + i] : 0.f;
             }
-            auto Zacc = [&](int i, int j) -> float & { return Z[i * DC_MAXLS + j]; };
+            auto Zacc = [&](int i, int j) -> float & { return Z[i * ldz + j]; };
             if (leaf_ql(s, dd, ee, Zacc, k0, lt) && k0 == 0) atomicAdd(&sh.fail, 1);
             // ascending order by selection (s <= 15), then emit WT[j][i] = Z(i, idx_j)
             for (int j = 0; j < s; ++j) {
@@ -261,7 +270,9 @@ __global__ __launch_bounds__(DC_THREADS, 5) void dc_kernel(int n, const float *_
         }
         __syncthreads();
         mark(5);
-        // P5: normalised eigenvectors of the rank-one update, U[kk][j] (kk pole, j root)
+        // P5: norms of the eigenvectors of the rank-one update, u_j = (zh_i / (d_i - lam_j))_i.  The
+        //     vectors themselves are regenerated inside the GEMM (two subtractions, a reciprocal and two
+        //     products per entry, hidden under the MFMA) instead of making a round trip through memory.
         if (act) {
             for (int j = tl; j < k; j += ts) {
                 float nrm = 0.f;
@@ -270,11 +281,7 @@ __global__ __launch_bounds__(DC_THREADS, 5) void dc_kernel(int n, const float *_
                     const float u = fdiv_fast(zh[a + i], (dl[a + i] - dorg) - tj);
                     nrm = fmaf(u, u, nrm);
                 }
-                const float inv = 1.0f / sqrtf(nrm);
-                for (int i = 0; i < k; ++i) {
-                    const float u = fdiv_fast(zh[a + i], (dl[a + i] - dorg) - tj);
-                    U[(int64_t)(a + i) * n + a + j] = u * inv;
-                }
+                un[a + j] = 1.0f / sqrtf(nrm);
             }
         }
         __syncthreads();
@@ -297,6 +304,7 @@ __global__ __launch_bounds__(DC_THREADS, 5) void dc_kernel(int n, const float *_
             }
             for (int i = tid; i < w; i += DC_THREADS) lamn[pa + i] = lam[pa + i];
         }
+        mark(10);
         {
             const int wave = tid >> 6, lane = tid & 63;
             const int r = lane & 31, kh = lane >> 5;
@@ -304,45 +312,55 @@ __global__ __launch_bounds__(DC_THREADS, 5) void dc_kernel(int n, const float *_
             for (int mm = 0; mm < nm; ++mm) {
                 const int ma = bn[2 * mm], mc = bn[2 * mm + 2];
                 const int mnn = mc - ma, mk = sh.kk[mm];
-                const int tm = (mk + 31) >> 5, tn = (mnn + 31) >> 5;
+                // work unit: two stacked 32 x 32 tiles (64 roots j) x 32 rows i; the B operand
+                // (source columns, the only memory stream) is shared by the pair, the A operand
+                // U[kk][j] = zh_kk / ((d_kk - d_org(j)) - tau_j) / ||u_j|| is generated in registers
+                const int tm2 = (mk + 63) >> 6, tn = (mnn + 31) >> 5;
                 const int first = (wave - gbase) & 3;
-                gbase += tm * tn;
-                for (int t = first; t < tm * tn; t += DC_THREADS / 64) {
-                    const int j0 = (t / tn) * 32, i0 = (t % tn) * 32;
-                    const bool jv = (j0 + r) < mk, iv = (i0 + r) < mnn;
-                    f32x16 acc = {0};
-                    const int jo = jv ? j0 + r : 0, io = iv ? i0 + r : 0;
-                    // 8 K-steps per batch (the operands sit in L2, ~1 us away)
-                    auto ld1 = [&](int k0, int s8, float &av, float &bv) {
-                        const int kq = k0 + 2 * s8 + kh;
-                        const bool kv = kq < mk;
-                        const int kc = kv ? kq : 0;
-                        // A[j][kk] = U[kk][j]; B[kk][i] = WTsrc[col(kk)][i]
-                        const float a_ = U[(ma + kc) * n + ma + jo];
-                        const float b_ = Ws[(ma + cidx[ma + kc]) * n + ma + io];
-                        av = (kv && jv) ? a_ : 0.f;
-                        bv = (kv && iv) ? b_ : 0.f;
-                    };
-                    auto ld8 = [&](int k0, float (&av)[8], float (&bv)[8]) {
+                gbase += tm2 * tn;
+                for (int t = first; t < tm2 * tn; t += DC_THREADS / 64) {
+                    const int j0 = (t / tn) * 64, i0 = (t % tn) * 32;
+                    const bool two = j0 + 32 < mk;
+                    const bool jv0 = (j0 + r) < mk, jv1 = (j0 + 32 + r) < mk, iv = (i0 + r) < mnn;
+                    const int ja = ma + (jv0 ? j0 + r : 0), jb = ma + (jv1 ? j0 + 32 + r : 0);
+                    const float dorg0 = dl[ma + org[ja]], tau0 = tau[ja], inv0 = jv0 ? un[ja] : 0.f;
+                    const float dorg1 = dl[ma + org[jb]], tau1 = tau[jb], inv1 = jv1 ? un[jb] : 0.f;
+                    const int io = iv ? i0 + r : 0;
+                    f32x16 acc0 = {0}, acc1 = {0};
+                    for (int k0 = 0; k0 < mk; k0 += 32) {   // 16 K-steps per batch: all loads first
+                        float bv[16];
 #pragma unroll
-                        for (int s8 = 0; s8 < 8; ++s8) ld1(k0, s8, av[s8], bv[s8]);
-                    };
-                    for (int k0 = 0; k0 < mk; k0 += 16) {   // loads of a whole batch first, then its MFMAs
-                        float av[8], bv[8];
-                        ld8(k0, av, bv);
+                        for (int s16 = 0; s16 < 16; ++s16) {
+                            const int kq = k0 + 2 * s16 + kh;
+                            const bool kv = kq < mk;
+                            const float b_ = Ws[(ma + cidx[ma + (kv ? kq : 0)]) * n + ma + io];
+                            bv[s16] = (kv && iv) ? b_ : 0.f;
+                        }
 #pragma unroll
-                        for (int s8 = 0; s8 < 8; ++s8)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s8], bv[s8], acc, 0, 0, 0);
+                        for (int s16 = 0; s16 < 16; ++s16) {
+                            const int kq = k0 + 2 * s16 + kh;
+                            const bool kv = kq < mk;
+                            const int kc = ma + (kv ? kq : 0);
+                            const float zk = kv ? zh[kc] : 0.f, dk = dl[kc];
+                            const float a0 = kv ? fdiv_fast(zk, (dk - dorg0) - tau0) * inv0 : 0.f;
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[s16], acc0, 0, 0, 0);
+                            if (two) {
+                                const float a1 = kv ? fdiv_fast(zk, (dk - dorg1) - tau1) * inv1 : 0.f;
+                                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[s16], acc1, 0, 0, 0);
+                            }
+                        }
                     }
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int j = j0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
                         const int i = i0 + r;
-                        if (j < mk && i < mnn) Wd[(int64_t)(ma + rnk[ma + j]) * n + ma + i] = acc[q];
+                        if (j < mk && i < mnn) Wd[(ma + rnk[ma + j]) * n + ma + i] = acc0[q];
+                        if (j + 32 < mk && i < mnn) Wd[(ma + rnk[ma + j + 32]) * n + ma + i] = acc1[q];
                     }
                 }
             }
         }
+        mark(11);
         __syncthreads();
         mark(7);
         // P7: commit eigenvalues and block boundaries
@@ -438,7 +456,7 @@ __global__ __launch_bounds__(256) void vgemm_kernel(int D, const float *__restri
 size_t dc_lds_bytes(int n) {
     const int NP = (n + 3) & ~3;
     const size_t nleaf = (size_t)(n / DC_LS > 0 ? n / DC_LS : 1);
-    size_t leaf = nleaf * DC_MAXLS * DC_MAXLS + nleaf * 2 * DC_MAXLS;
+    size_t leaf = dc_leafz_floats((int)nleaf) + nleaf * 2 * DC_MAXLS;
     if (leaf < 32 * 33) leaf = 32 * 33;   // the final transpose reuses the leaf scratch as a tile
     return sizeof(float) * 11 * NP + sizeof(int) * 5 * NP + sizeof(DcRot) * NP + sizeof(float) * leaf;
 }
@@ -451,15 +469,17 @@ int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st) 
         return ADMMNET_E_ARG;
     }
     const size_t lds = dc_lds_bytes(n);
-    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dc_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const int occ = getenv("ADMMNET_DC_OCC") ? atoi(getenv("ADMMNET_DC_OCC")) : 5;   // tuning knob
+    auto kern = occ >= 8 ? dc_kernel<8> : occ == 6 ? dc_kernel<6> : dc_kernel<5>;
+    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
     static const bool timing = getenv("ADMMNET_DC_TIMING") != nullptr;   // developer aid, never on by default
     unsigned long long *ptime = nullptr;
     if (timing) {
         ADMM_HIP(hipMalloc(&ptime, 64 * sizeof(unsigned long long)));
         ADMM_HIP(hipMemsetAsync(ptime, 0, 64 * sizeof(unsigned long long), st));
     }
-    hipLaunchKernelGGL(dc_kernel, dim3((unsigned)nb), dim3(DC_THREADS), lds, st, n, ws.dT, ws.eT, ws.Wdc, ws.w,
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(DC_THREADS), lds, st, n, ws.dT, ws.eT, ws.Wdc, ws.w,
                        ws.w0, ws.logn, status, ptime);
     ADMM_HIP(hipGetLastError());
     if (timing) {
@@ -467,10 +487,10 @@ int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st) 
         ADMM_HIP(hipMemcpyAsync(h, ptime, sizeof(h), hipMemcpyDeviceToHost, st));
         ADMM_HIP(hipStreamSynchronize(st));
         ADMM_HIP(hipFree(ptime));
-        static const char *nm[10] = {"init", "leaves", "P1 sort", "P2 scan", "P3 rot+secular", "P4 zhat+rank",
-                                     "P5 U", "P6 copy+gemm", "P7 commit", "final transpose"};
+        static const char *nm[12] = {"init", "leaves", "P1 sort", "P2 scan", "P3 rot+secular", "P4 zhat+rank",
+                                     "P5 U", "P6 barrier wait", "P7 commit", "final transpose", "P6 copy", "P6 gemm"};
         fprintf(stderr, "[dc timing] n=%d nb=%lld  mean cycles per workgroup:\n", n, (long long)nb);
-        for (int i = 0; i < 10; ++i) fprintf(stderr, "   %-16s %10.0f\n", nm[i], (double)h[i] / (double)nb);
+        for (int i = 0; i < 12; ++i) fprintf(stderr, "   %-16s %10.0f\n", nm[i], (double)h[i] / (double)nb);
         for (int l = 0; l < 6; ++l) {
             fprintf(stderr, "   level %d:", l);
             for (int q = 0; q < 7; ++q) fprintf(stderr, " %8.0f", (double)h[16 + 8 * l + q] / (double)nb);

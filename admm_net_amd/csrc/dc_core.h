@@ -137,6 +137,16 @@ struct DcRot {
     float c, s;
 };
 
+// 1 / sqrt(x): v_rsq_f32 plus one Newton step on the device
+HD float rsqrt_nr(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rsqf(x);
+    return r * fmaf(-0.5f * x * r, r, 1.5f);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+
 // The scan is a serial chain over (pj, d_pj, z_pj): that state is carried in registers and the
 // next (d, z) pair is fetched one step ahead, so the chain never waits on the LDS.  `dzmax` =
 // max(max |ds|, max |zs|) is supplied by the caller (team reduction on the device).
@@ -176,14 +186,24 @@ HD void deflate_scan_tol(int nn, float rho, float dmax, float zmax, FA ds, FA zs
             zpj = zj;
             continue;
         }
-        // type 2: two (nearly) equal poles -> rotate z_pj into z_j
-        float s = zpj, c = zj;
-        const float tau = sqrtf(c * c + s * s);
+        // type 2: two (nearly) equal poles -> rotate z_pj into z_j.  With c = z_j / tau, s = -z_pj / tau
+        // the test |t c s| <= tol reads |t z_j z_pj| <= tol tau^2: no square root unless it deflates.
+        const float q = zj * zj + zpj * zpj;
         const float t = dj - dpj;
-        const float itau = recip_nr(tau);
-        c *= itau;
-        s = -s * itau;
-        if (fabsf(t * c * s) <= tol) {
+        if (!(fabsf(t * zj * zpj) <= tol * q) || q < 1e-30f) {   // (q guard: keep v_rsq_f32 in range)
+            dl[k] = dpj;
+            zl[k] = zpj;
+            src[k] = pj;
+            ++k;
+            pj = j;
+            dpj = dj;
+            zpj = zj;
+            continue;
+        }
+        const float itau = rsqrt_nr(q);
+        const float tau = q * itau;
+        const float c = zj * itau, s = -zpj * itau;
+        {
             DcRot r;
             r.pa = pj;
             r.pb = j;
@@ -196,14 +216,6 @@ HD void deflate_scan_tol(int nn, float rho, float dmax, float zmax, FA ds, FA zs
             dpj = dpj * s * s + dj * c * c;
             zpj = tau;
             pj = j;
-        } else {
-            dl[k] = dpj;
-            zl[k] = zpj;
-            src[k] = pj;
-            ++k;
-            pj = j;
-            dpj = dj;
-            zpj = zj;
         }
     }
     if (pj >= 0) {

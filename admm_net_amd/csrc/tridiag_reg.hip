@@ -225,24 +225,30 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
 
 // reflector u restricted to my columns (blocks b >= B0), from the global image
 // (float2 storage: arrays of ext_vector types that live across calls end up in scratch)
-template <int NA, int B0>
+// FULL (D == 16 NA): no padding columns, the loads need no predicate (u = -1, past the last step,
+// reads row 0 and is never used).
+template <int NA, int B0, bool FULL>
 __device__ __forceinline__ void q_load(float2 (&vn)[NA], int u, int D, const float2 *__restrict__ Mg) {
     const int tj = threadIdx.x & 15;
+    const float2 *row = Mg + (int64_t)(u < 0 ? 0 : u) * D + tj;
 #pragma unroll
     for (int b = B0; b < NA; ++b) {
-        const int j = 16 * b + tj;
-        vn[b] = (j < D && u >= 0) ? Mg[(int64_t)(u < 0 ? 0 : u) * D + j] : make_float2(0.f, 0.f);
+        if constexpr (FULL) {
+            vn[b] = row[16 * b];
+        } else {
+            vn[b] = (16 * b + tj < D && u >= 0) ? row[16 * b] : make_float2(0.f, 0.f);
+        }
     }
 }
 
 // P <- P (I - conj(tau) v v^H) for the reflector with unit entry u, 16*A0 <= u < 16*(A0+1).  `vc`
 // holds reflector u on entry and reflector u - 1 on exit (its loads fly during this step).
-template <int NA, int A0>
+template <int NA, int A0, bool FULL>
 __device__ __forceinline__ void q_step(float2 (&m)[NA][NA], const TrShared<NA> &sh, int u, int D,
                                        const float2 *__restrict__ Mg, float2 (&vcs)[NA]) {
     constexpr int AP = A0 > 0 ? A0 - 1 : 0;
     float2 vn[NA];
-    q_load<NA, AP>(vn, u - 1, D, Mg);
+    q_load<NA, AP, FULL>(vn, u - 1, D, Mg);
     const float2 tau = sh.taus[u];
     if (!(tau.x == 0.f && tau.y == 0.f)) {
         v2 vc[NA], vj[NA], y[NA];
@@ -279,11 +285,12 @@ struct TrPhases {
         for (int u = 16 * A0; u < hi; ++u) tr_step<NA, A0>(m, sh, u, D, corner, ag, Mg, dcol, ecol);
         if constexpr (A0 + 1 < NA) TrPhases<NA, A0 + 1>::forward(m, sh, D, corner, ag, Mg, dcol, ecol);
     }
+    template <bool FULL>
     static __device__ __forceinline__ void backward(float2 (&m)[NA][NA], const TrShared<NA> &sh, int D,
                                                     const float2 *Mg, float2 (&vc)[NA]) {
-        if constexpr (A0 + 1 < NA) TrPhases<NA, A0 + 1>::backward(m, sh, D, Mg, vc);
+        if constexpr (A0 + 1 < NA) TrPhases<NA, A0 + 1>::template backward<FULL>(m, sh, D, Mg, vc);
         const int hi = min(16 * (A0 + 1), D);
-        for (int u = hi - 1; u >= 16 * A0; --u) q_step<NA, A0>(m, sh, u, D, Mg, vc);
+        for (int u = hi - 1; u >= 16 * A0; --u) q_step<NA, A0, FULL>(m, sh, u, D, Mg, vc);
     }
 };
 
@@ -334,8 +341,13 @@ __global__ __launch_bounds__(TR_THREADS, 2) void tridiag_reg_kernel(int D, float
 #pragma unroll
         for (int b = 0; b < NA; ++b) m[a][b] = make_float2((a == b && ti == tj) ? 1.f : 0.f, 0.f);
     float2 vc[NA];
-    q_load<NA, 0>(vc, D - 1, D, Mg);
-    TrPhases<NA, 0>::backward(m, sh, D, Mg, vc);
+    if (D == 16 * NA) {   // uniform
+        q_load<NA, 0, true>(vc, D - 1, D, Mg);
+        TrPhases<NA, 0>::template backward<true>(m, sh, D, Mg, vc);
+    } else {
+        q_load<NA, 0, false>(vc, D - 1, D, Mg);
+        TrPhases<NA, 0>::template backward<false>(m, sh, D, Mg, vc);
+    }
     // ---------------- QT[c][rho] = Q[rho][c] = conj(P[c][rho]) ---------------------------------
     float *q = QV + bm * ((int64_t)n * 2 * D);
 #pragma unroll
