@@ -158,6 +158,13 @@ static bool fuse_back(int D, const Ws &ws) {
     return on && ws.Wdc && back_rebuild_supported(D);
 }
 
+// The first G-layer (Z = 0) sees a plain arrowhead matrix: arrow.hip solves it directly in O(n^2)
+// (D <= 128).  ADMMNET_ARROW=0 sends it down the dense path like every other layer.
+static bool use_arrow(int D) {
+    static const bool on = !(getenv("ADMMNET_ARROW") && atoi(getenv("ADMMNET_ARROW")) == 0);
+    return on && arrow_rebuild_supported(D);
+}
+
 static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool with_v = true) {
     int rc;
     if ((rc = launch_tridiag(D, nb, ws, st))) return rc;
@@ -346,6 +353,13 @@ int admmnet_layer_front(const admmnet_cfg *cfg, const float *W, int32_t k, const
     const int cur = k & 1;
     for (int64_t b0 = 0; b0 < B; b0 += ws.chunk) {
         const int64_t nb = (B - b0 < ws.chunk) ? (B - b0) : ws.chunk;
+        if (k == 0 && use_arrow(D)) {   // Z = 0: arrowhead, no matrix is ever formed
+            if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, ws, false, st, true))) return rc;
+            if ((rc = launch_arrow_rebuild(D, nb, lw, ws.phi[cur] + b0 * D, ws.h[cur] + b0 * D, ws.G + b0 * n * n,
+                                           ws.rn + b0, nullptr, status, st)))
+                return rc;
+            continue;
+        }
         if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, ws, false, st))) return rc;
         const bool fused = fuse_back(D, ws);
         if ((rc = eig_chunk(D, nb, ws, status, st, !fused))) return rc;
@@ -438,6 +452,13 @@ int admmnet_glayer_f32(const admmnet_cfg *cfg, const float *lw, const void *phi,
         const int64_t nb = (B - b0 < ws.chunk) ? (B - b0) : ws.chunk;
         const float2 *ph = (const float2 *)phi + b0 * D;
         const float2 *Zc = Z ? (const float2 *)Z + b0 * n * n : nullptr;
+        if (!Zc && use_arrow(D)) {
+            if ((rc = launch_arrow_rebuild(D, nb, lw, ph, h + b0 * D, (float2 *)G_out + b0 * n * n,
+                                           rn_out ? rn_out + b0 : rn_tmp + b0, w_out ? w_out + b0 * n : nullptr,
+                                           status, st)))
+                return rc;
+            continue;
+        }
         if ((rc = launch_build_block(D, nb, sc[S_CORNER_G], sc[S_INV_RHO_G], ph, h + b0 * D, Zc, ws, st))) return rc;
         const bool fused = fuse_back(D, ws);
         if ((rc = eig_chunk(D, nb, ws, status, st, !fused))) return rc;

@@ -1,0 +1,306 @@
+// arrow.hip -- first G-layer (Z = 0): direct eigensolver for the Hermitian arrowhead
+//     A = C = [[diag h, phi], [phi^H, corner]]          (/root/reference/admm_net.py:273-288)
+// fused with the rebuild G = V f(Lambda) V^H + ||G - C||_F (admm_net.py:303-354, 400-403, 454), D <= 128.
+//
+// The dense path (tridiagonalise, divide & conquer, back-transform) costs O(n^3) per matrix; an
+// arrowhead's eigenpairs follow from one secular equation in O(n^2) (arrow_core.h).  One 256-thread
+// workgroup per matrix:
+//   P1 sort h (rank counting), |phi| and phases          P5 zeta-hat (Loewner), ranks of all eigenvalues
+//   P2 deflation scan (one thread, as in the D&C merge)  P6 norms, eigenvalue map f(lambda)
+//   P4 secular roots, one thread per root                P7 eigenvectors written straight into LDS as VT[c][rho]
+//   P8 deflation rotations undone, phases applied        then rebuild_from_lds (shared with backrebuild.hip)
+// V never exists in memory; the only HBM traffic is phi, h in and G out.
+#include <cstdio>
+#include <cstdlib>
+
+#include "common.h"
+
+#include "arrow_core.h"
+#include "rebuild_lds.h"
+
+namespace admmnet {
+
+constexpr int AR_THREADS = 256;
+
+struct ArShared {
+    int k, nrot;
+    int mx[2];
+    float znorm;
+};
+
+__host__ __device__ inline size_t ar_np(int D) { return (size_t)((D + 1 + 3) & ~3); }
+// float arrays of length NP: hraw zraw phr phim ds zs dl zl tau zh vals x0 (12) ; int arrays: perm src org rnk kidx (5)
+__host__ __device__ inline size_t ar_lds_bytes(const BrGeom &g) {
+    const size_t NP = ar_np(g.D);
+    return sizeof(float) * (g.vt_floats() + g.small_floats() + 12 * NP) + sizeof(int) * 5 * NP + sizeof(DcRot) * NP;
+}
+
+__global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
+    int D, const float *__restrict__ lw, const float2 *__restrict__ phi, const float *__restrict__ h,
+    float2 *__restrict__ G, float *__restrict__ rn, float *__restrict__ w_out, int32_t *__restrict__ status,
+    unsigned long long *__restrict__ ptime) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ ArShared sh;
+    // developer phase timer (ADMMNET_AR_TIMING=1): cycles of thread 0 between marks
+    long long t_prev = ptime ? clock64() : 0;
+    auto mark = [&](int id) {
+        if (ptime && threadIdx.x == 0) {
+            const long long t_now = clock64();
+            atomicAdd(&ptime[id], (unsigned long long)(t_now - t_prev));
+            t_prev = t_now;
+        }
+    };
+    const BrGeom g(D);
+    const int n = g.n, Dp = g.Dp, VP = g.VP;
+    const int NP = (int)ar_np(D);
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const float alpha = lw[S_CORNER_G];   // corner of C = 1 / (lambda^2 + eps), admm_net.py:271
+    float *VTl = reinterpret_cast<float *>(smem);
+    float *fs = VTl + g.vt_floats();
+    float *w0f = fs + ((n + 4) & ~3);
+    float *z0s = w0f + ((n + 4) & ~3);
+    float *rowb = z0s + ((n + 4) & ~3);
+    float *redb = rowb + 2 * Dp;
+    float *hraw = redb + 8;
+    float *zraw = hraw + NP;
+    float *phr = zraw + NP;
+    float *phim = phr + NP;
+    float *ds = phim + NP;
+    float *zs = ds + NP;
+    float *dl = zs + NP;
+    float *zl = dl + NP;
+    float *tau = zl + NP;
+    float *zh = tau + NP;
+    float *vals = zh + NP;
+    float *x0 = vals + NP;
+    int *perm = reinterpret_cast<int *>(x0 + NP);
+    int *src = perm + NP;
+    int *org = src + NP;
+    int *rnk = org + NP;
+    int *kidx = rnk + NP;
+    DcRot *rot = reinterpret_cast<DcRot *>(kidx + NP);
+
+    // ---- P0: load, moduli and phases
+    if (tid == 0) {
+        sh.mx[0] = __float_as_int(fabsf(alpha));
+        sh.mx[1] = 0;
+    }
+    for (int i = tid; i < D; i += AR_THREADS) {
+        const float2 z = phi[b * D + i];
+        const float a = sqrtf(z.x * z.x + z.y * z.y);
+        const float ia = a > 0.f ? 1.0f / a : 0.f;
+        hraw[i] = h[b * D + i];
+        zraw[i] = a;
+        phr[i] = a > 0.f ? z.x * ia : 1.f;
+        phim[i] = a > 0.f ? z.y * ia : 0.f;
+    }
+    __syncthreads();
+    // ---- P1: sort h ascending (stable rank counting)
+    for (int i = tid; i < D; i += AR_THREADS) {
+        const float v = hraw[i];
+        int r = 0;
+        for (int q = 0; q < D; ++q) {
+            const float u = hraw[q];
+            r += (u < v) || (u == v && q < i);
+        }
+        perm[r] = i;
+        ds[r] = v;
+        zs[r] = zraw[i];
+        atomicMax(&sh.mx[0], __float_as_int(fabsf(v)));
+        atomicMax(&sh.mx[1], __float_as_int(zraw[i]));
+    }
+    __syncthreads();
+    // ---- P2: deflation.  Usual case: nothing deflates (distinct h, non-zero phi) -- checked in parallel;
+    //      otherwise the serial scan of the D&C merge (one thread)
+    {
+        const float dmax = __int_as_float(sh.mx[0]), zmax = __int_as_float(sh.mx[1]);
+        int trig = 0;
+        for (int p = tid; p < D; p += AR_THREADS) trig |= deflate_triggers(p, 1.0f, dmax, zmax, ds, zs) ? 1 : 0;
+        if (__syncthreads_or(trig)) {
+            if (tid == 0) {
+                int k = 0, nr = 0;
+                deflate_scan_tol(D, 1.0f, dmax, zmax, ds, zs, dl, zl, src, rot, k, nr);
+                sh.k = k;
+                sh.nrot = nr;
+            }
+        } else {
+            for (int p = tid; p < D; p += AR_THREADS) {
+                dl[p] = ds[p];
+                zl[p] = zs[p];
+                src[p] = p;
+            }
+            if (tid == 0) {
+                sh.k = D;
+                sh.nrot = 0;
+            }
+        }
+    }
+    __syncthreads();
+    mark(0);
+    const int k = sh.k, nrot = sh.nrot;
+    // slots: 0..k roots, p + 1 for the deflated pole at scan position p in [k, D)
+    for (int p = k + tid; p < D; p += AR_THREADS) vals[p + 1] = dl[p];
+    for (int p = tid; p < D; p += AR_THREADS) kidx[src[p]] = (p < k) ? p : -(p + 1) - 1;   // sorted position -> pole / slot
+    if (tid < 64) {   // ||zeta|| of the surviving poles
+        float s = 0.f;
+        for (int i = tid; i < k; i += 64) s = fmaf(zl[i], zl[i], s);
+        s = wave_sum(s);
+        if (tid == 0) sh.znorm = sqrtf(s);
+    }
+    __syncthreads();
+    // ---- P4: secular roots
+    if (k == 0) {
+        if (tid == 0) vals[0] = alpha;
+    } else {
+        const float znorm = sh.znorm;
+        for (int j = tid; j <= k; j += AR_THREADS) {
+            int o;
+            float t;
+            arrow_root(k, j, alpha, znorm, dl, zl, o, t);
+            org[j] = o;
+            tau[j] = t;
+            vals[j] = dl[o] + t;
+        }
+    }
+    __syncthreads();
+    mark(1);
+    // ---- P5: zeta-hat, final (ascending, stable) positions of all n eigenvalues
+    for (int i = tid; i < k; i += AR_THREADS) zh[i] = arrow_zhat(k, i, dl, org, tau);
+    for (int s = tid; s < n; s += AR_THREADS) {
+        const float v = vals[s];
+        int r = 0;
+        for (int q = 0; q < n; ++q) {
+            const float u = vals[q];
+            r += (u < v) || (u == v && q < s);
+        }
+        rnk[s] = r;
+    }
+    __syncthreads();
+    // ---- P6: norms; eigenvalue map and arrow-row entries in final order
+    {
+        const LayerLayout L{D};
+        const float thr = lw[S_THR];
+        const float *vn = lw + L.off_vn();
+        for (int s = tid; s < n; s += AR_THREADS) {
+            float xa = 0.f;   // arrow component of eigenvector s
+            if (s <= k) {
+                float nrm = 1.f;
+                if (k > 0) {
+                    const float dorg = dl[org[s]], ts = tau[s];
+                    for (int i = 0; i < k; ++i) {
+                        const float v = fdiv_fast(zh[i], (dorg - dl[i]) + ts);   // zhat_i / (lam_s - d_i)
+                        nrm = fmaf(v, v, nrm);
+                    }
+                }
+                xa = 1.0f / sqrtf(nrm);
+            }
+            x0[s] = xa;
+            const int c = rnk[s];
+            const float lam = vals[s];
+            const float f = br_eig_map(lam, thr, vn);
+            fs[c] = f;
+            w0f[c] = xa * f;
+            z0s[c] = xa;
+            if (w_out) w_out[b * n + c] = lam;
+        }
+        if (tid == 0) {
+            fs[n] = 0.f;
+            w0f[n] = 0.f;
+            z0s[n] = 0.f;
+        }
+    }
+    __syncthreads();
+    mark(2);
+    // ---- P7: eigenvectors in the rotated real basis, straight into VT[c][column of ORIGINAL index]
+    //      thread = original index i (both planes' padding columns are zeroed as well)
+    int *ipos = reinterpret_cast<int *>(hraw);   // inverse permutation (hraw is dead since P1)
+    for (int p = tid; p < D; p += AR_THREADS) ipos[perm[p]] = p;
+    __syncthreads();
+    for (int i = tid; i < Dp; i += AR_THREADS) {
+        float *colr = VTl + i, *coli = VTl + Dp + i;
+        if (i >= D) {
+            for (int c = 0; c < n; ++c) {
+                colr[c * VP] = 0.f;
+                coli[c * VP] = 0.f;
+            }
+            continue;
+        }
+        const int kd = kidx[ipos[i]];
+        if (kd >= 0) {   // surviving pole kd: component zhat x0_s / (lam_s - d) in every root's eigenvector
+            const float zi = zh[kd], di = dl[kd];
+            for (int s = 0; s <= k; ++s) {
+                const float v = fdiv_fast(zi, (dl[org[s]] - di) + tau[s]) * x0[s];
+                colr[rnk[s] * VP] = v;
+            }
+            for (int s = k + 1; s < n; ++s) colr[rnk[s] * VP] = 0.f;
+        } else {         // deflated pole: unit vector of slot -(kd) - 1
+            const int slot = -kd - 1;
+            for (int s = 0; s < n; ++s) colr[rnk[s] * VP] = (s == slot) ? 1.f : 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- P8: undo the deflation rotations (reverse order, v = G^T v'), thread = eigenvector row c
+    for (int c = tid; c < n; c += AR_THREADS) {
+        float *row = VTl + c * VP;
+        for (int r = nrot - 1; r >= 0; --r) {
+            const DcRot rr = rot[r];
+            const int ia = perm[rr.pa], ib = perm[rr.pb];
+            const float a = row[ia], bb = row[ib];
+            row[ia] = rr.c * a - rr.s * bb;
+            row[ib] = rr.s * a + rr.c * bb;
+        }
+    }
+    __syncthreads();
+    // phases: (re, im) planes
+    for (int i = tid; i < D; i += AR_THREADS) {
+        float *colr = VTl + i, *coli = VTl + Dp + i;
+        const float pr = phr[i], pi = phim[i];
+        for (int c = 0; c < n; ++c) {
+            const float x = colr[c * VP];
+            colr[c * VP] = x * pr;
+            coli[c * VP] = x * pi;
+        }
+    }
+    __syncthreads();
+    mark(3);
+    (void)status;
+    rebuild_from_lds(g, b, lw, VTl, fs, w0f, z0s, rowb, redb, phi, h, G, rn, [&](int id) { mark(id); });
+}
+
+bool arrow_rebuild_supported(int D) { return D >= 1 && D <= 128; }
+
+int launch_arrow_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G, float *rn,
+                         float *w_out, int32_t *status, hipStream_t st) {
+    ProfScope _prof(KC_REBUILD, st);
+    if (nb <= 0) return ADMMNET_OK;
+    if (!arrow_rebuild_supported(D)) {
+        set_error("arrow_rebuild: D=%d unsupported", D);
+        return ADMMNET_E_ARG;
+    }
+    const BrGeom g(D);
+    const size_t lds = ar_lds_bytes(g);
+    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(arrow_rebuild_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const bool timing = getenv("ADMMNET_AR_TIMING") != nullptr;   // developer aid, never on by default
+    unsigned long long *ptime = nullptr;
+    if (timing) {
+        ADMM_HIP(hipMalloc(&ptime, 16 * sizeof(unsigned long long)));
+        ADMM_HIP(hipMemsetAsync(ptime, 0, 16 * sizeof(unsigned long long), st));
+    }
+    hipLaunchKernelGGL(arrow_rebuild_kernel, dim3((unsigned)nb), dim3(AR_THREADS), lds, st, D, lw, phi, h, G, rn,
+                       w_out, status, ptime);
+    ADMM_HIP(hipGetLastError());
+    if (timing) {
+        unsigned long long hb[16];
+        ADMM_HIP(hipMemcpyAsync(hb, ptime, sizeof(hb), hipMemcpyDeviceToHost, st));
+        ADMM_HIP(hipStreamSynchronize(st));
+        ADMM_HIP(hipFree(ptime));
+        static const char *nm[6] = {"sort+deflate", "roots", "zhat+rank+norm", "vectors", "G tiles", "arrow+norm"};
+        fprintf(stderr, "[arrow_rebuild timing] D=%d nb=%lld  mean cycles per workgroup:\n", D, (long long)nb);
+        for (int i = 0; i < 6; ++i) fprintf(stderr, "   %-14s %10.0f\n", nm[i], (double)hb[i] / (double)nb);
+    }
+    return ADMMNET_OK;
+}
+
+}  // namespace admmnet

@@ -16,7 +16,11 @@
 //      rebuild.hip.
 // Against the unfused pair (dc.hip vgemm_kernel + rebuild.hip) this removes the VT round trip
 // through HBM (2 x 132 KB per matrix) and replaces L2-latency-bound operand loads by LDS reads.
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
+#include "rebuild_lds.h"
 
 namespace admmnet {
 
@@ -27,43 +31,40 @@ constexpr int BR_KS = 16;          // K rows per slab
 constexpr int BR_NCT = 5;          // eigenvector tiles: n <= 129 + padding
 constexpr int BR_AP = 32 * BR_NCT; // slab A row pitch (floats)
 
-__device__ __forceinline__ float br_eig_map(float w, float thr, const float *vn) {
-    // vn: w1[16] b1[16] w2[16] b2[1]   (same as rebuild.hip eig_map)
-    const float base = softplus_f(w - thr);
-    const float a = fabsf(w);
-    float acc = vn[48];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc = fmaf(vn[32 + j], fmaxf(fmaf(vn[j], a, vn[16 + j]), 0.f), acc);
-    return base * sigmoid_f(acc);
+// slab double buffer of phase A
+__host__ __device__ inline size_t br_slab_floats(const BrGeom &g) { return (size_t)2 * BR_KS * (BR_AP + g.BP); }
+__host__ __device__ inline size_t br_lds_bytes(const BrGeom &g) {
+    const size_t big = br_slab_floats(g) > g.vt_floats() ? br_slab_floats(g) : g.vt_floats();
+    return sizeof(float) * (big + g.small_floats());
 }
 
-struct BrGeom {
-    int D, n, NT, Dp, BP, VP;
-    __host__ __device__ explicit BrGeom(int D_) : D(D_), n(D_ + 1), NT((D_ + 31) / 32), Dp(32 * ((D_ + 31) / 32)) {
-        BP = 2 * Dp;       // slab B row pitch: real plane | imaginary plane, each padded to 32
-        VP = 2 * Dp + 4;   // VT row pitch in LDS
-    }
-    __host__ __device__ size_t slab_floats() const { return (size_t)2 * BR_KS * (BR_AP + BP); }
-    __host__ __device__ size_t vt_floats() const { return (size_t)n * VP; }
-    __host__ __device__ size_t small_floats() const { return (size_t)3 * ((n + 4) & ~3) + 2 * Dp + 8; }
-    __host__ __device__ size_t lds_bytes() const {
-        const size_t big = slab_floats() > vt_floats() ? slab_floats() : vt_floats();
-        return sizeof(float) * (big + small_floats());
-    }
-};
-
+// NCT = ceil(n / 32) eigenvector tiles (compile time: a run-time tile count puts a branch and an exposed LDS
+// wait in front of every MFMA pair)
+// NSLAB > 0: compile-time slab count (the slab loop is fully unrolled: with a loop back-edge the 160
+// accumulators are carried in VGPRs and copied to and from the AGPRs around every slab); 0: run-time count.
+template <int NCT, int NSLAB>
 __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     int D, const float *__restrict__ lw, const float *__restrict__ Wbuf, const float *__restrict__ QT,
     const float *__restrict__ wv, const float *__restrict__ w0v, const float2 *__restrict__ phi,
-    const float *__restrict__ h, float2 *__restrict__ G, float *__restrict__ rn) {
+    const float *__restrict__ h, float2 *__restrict__ G, float *__restrict__ rn,
+    unsigned long long *__restrict__ ptime) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // developer phase timer (ADMMNET_BR_TIMING=1): cycles of thread 0 between marks
+    long long t_prev = ptime ? clock64() : 0;
+    auto mark = [&](int id) {
+        if (ptime && threadIdx.x == 0) {
+            const long long t_now = clock64();
+            atomicAdd(&ptime[id], (unsigned long long)(t_now - t_prev));
+            t_prev = t_now;
+        }
+    };
     const BrGeom g(D);
     const int n = g.n, NT = g.NT, Dp = g.Dp, BP = g.BP, VP = g.VP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, kh = lane >> 5;
     const int64_t b = blockIdx.x;
     float *big = reinterpret_cast<float *>(smem);
-    const size_t bigf = g.slab_floats() > g.vt_floats() ? g.slab_floats() : g.vt_floats();
+    const size_t bigf = br_slab_floats(g) > g.vt_floats() ? br_slab_floats(g) : g.vt_floats();
     float *fs = big + bigf;                          // [n+1] f(lambda)
     float *w0f = fs + ((n + 4) & ~3);                // [n+1] w0 * f
     float *z0s = w0f + ((n + 4) & ~3);               // [n+1] w0
@@ -117,140 +118,78 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
             if (tid < BP) sb[q * BP + tid] = rb[q];
         }
     };
-    f32x16 accR[BR_NCT], accI[BR_NCT];
+    f32x16 accR[NCT], accI[NCT];
 #pragma unroll
-    for (int ct = 0; ct < BR_NCT; ++ct) {
+    for (int ct = 0; ct < NCT; ++ct) {
         accR[ct] = f32x16{0};
         accI[ct] = f32x16{0};
     }
-    const int nct = (n + 31) / 32;
     const bool wact = wave < NT;   // this wave owns row-tile `wave` of V
-    const int nslab = (D + BR_KS - 1) / BR_KS;
+    const int nslab = NSLAB > 0 ? NSLAB : (D + BR_KS - 1) / BR_KS;
+    mark(0);
     gload(0);
     lstore(0);
     __syncthreads();
-    for (int s = 0; s < nslab; ++s) {
+    mark(1);
+#pragma unroll
+    for (int s = 0; s < (NSLAB > 0 ? NSLAB : nslab); ++s) {
         const int buf = s & 1;
         if (s + 1 < nslab) gload((s + 1) * BR_KS);
         if (wact) {
             const float *sa = slabA + (size_t)buf * BR_KS * BR_AP, *sb = slabB + (size_t)buf * BR_KS * BP;
+            // operands of k-step kk + 1 are read from LDS before the MFMAs of k-step kk are issued
+            // (sched_barrier pins that order: left alone, the scheduler sinks every read to just before
+            // its first use and each MFMA pair then waits out a full LDS latency)
+            const float *sap = sa + kh * BR_AP + l32, *sbp = sb + kh * BP + 32 * wave + l32;
+            float a_cur[NCT], a_nxt[NCT], bR_cur, bI_cur, bR_nxt = 0.f, bI_nxt = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) a_cur[ct] = sap[32 * ct];
+            bR_cur = sbp[0];
+            bI_cur = sbp[Dp];
 #pragma unroll
             for (int kk = 0; kk < BR_KS / 2; ++kk) {
-                const int row = 2 * kk + kh;
-                const float bR = sb[row * BP + 32 * wave + l32];
-                const float bI = sb[row * BP + Dp + 32 * wave + l32];
+                if (kk + 1 < BR_KS / 2) {
 #pragma unroll
-                for (int ct = 0; ct < BR_NCT; ++ct) {
-                    if (ct < nct) {
-                        const float a = sa[row * BR_AP + 32 * ct + l32];
-                        accR[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bR, accR[ct], 0, 0, 0);
-                        accI[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bI, accI[ct], 0, 0, 0);
-                    }
+                    for (int ct = 0; ct < NCT; ++ct) a_nxt[ct] = sap[2 * (kk + 1) * BR_AP + 32 * ct];
+                    bR_nxt = sbp[2 * (kk + 1) * BP];
+                    bI_nxt = sbp[2 * (kk + 1) * BP + Dp];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    accR[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ct], bR_cur, accR[ct], 0, 0, 0);
+                    accI[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ct], bI_cur, accI[ct], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) a_cur[ct] = a_nxt[ct];
+                bR_cur = bR_nxt;
+                bI_cur = bI_nxt;
             }
         }
         if (s + 1 < nslab) lstore(buf ^ 1);
         __syncthreads();
     }
 
+    mark(2);
     // ---------------- phase B: accumulators -> VT[c][rho'] in LDS ------------------------------------
     if (wact) {
 #pragma unroll
-        for (int ct = 0; ct < BR_NCT; ++ct) {
-            if (ct < nct) {
+        for (int ct = 0; ct < NCT; ++ct) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int c = 32 * ct + (q & 3) + 8 * (q >> 2) + 4 * kh;
-                    if (c < n) {
-                        VTl[c * VP + 32 * wave + l32] = accR[ct][q];
-                        VTl[c * VP + Dp + 32 * wave + l32] = accI[ct][q];
-                    }
+            for (int q = 0; q < 16; ++q) {
+                const int c = 32 * ct + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                if (c < n) {
+                    VTl[c * VP + 32 * wave + l32] = accR[ct][q];
+                    VTl[c * VP + Dp + 32 * wave + l32] = accI[ct][q];
                 }
             }
         }
     }
     __syncthreads();
+    mark(3);
 
-    // ---------------- phase C: G = V f V^H, lower-triangle tiles, operands from LDS -------------------
-    float2 *Gb = G + b * (int64_t)n * n;
-    float acc2 = 0.f;
-    const int ntiles = NT * (NT + 1) / 2;
-    for (int t = wave; t < ntiles; t += BR_THREADS / 64) {
-        int I = 0;
-        while ((I + 1) * (I + 2) / 2 <= t) ++I;
-        const int J = t - I * (I + 1) / 2;
-        const int i0 = 32 * I, j0 = 32 * J;
-        f32x16 aRe = {0}, aIm = {0};
-#pragma unroll 4
-        for (int kk = 0; kk < n; kk += 2) {
-            const int c = kk + kh;
-            const bool cv = c < n;
-            const int cc = cv ? c : 0;
-            const float fc = cv ? fs[cc] : 0.f;
-            const float *row = VTl + cc * VP;
-            const float xr = row[i0 + l32] * fc, xi = row[Dp + i0 + l32] * fc;
-            float yr = row[j0 + l32], yi = row[Dp + j0 + l32];
-            yr = cv ? yr : 0.f;
-            yi = cv ? yi : 0.f;
-            aRe = __builtin_amdgcn_mfma_f32_32x32x2f32(xr, yr, aRe, 0, 0, 0);
-            aRe = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, yi, aRe, 0, 0, 0);
-            aIm = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, yr, aIm, 0, 0, 0);
-            aIm = __builtin_amdgcn_mfma_f32_32x32x2f32(-xr, yi, aIm, 0, 0, 0);
-        }
-        // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int gi = i0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
-            const int gj = j0 + l32;
-            if (gi < D && gj < D && gi >= gj) {
-                const float re = aRe[q], im = aIm[q];
-                if (gi == gj) {
-                    Gb[(int64_t)gi * n + gj] = make_float2(re, 0.f);
-                    const float d = re - h[b * D + gi];
-                    acc2 += d * d;
-                } else {
-                    Gb[(int64_t)gi * n + gj] = make_float2(re, im);
-                    Gb[(int64_t)gj * n + gi] = make_float2(re, -im);
-                    acc2 += 2.f * (re * re + im * im);
-                }
-            }
-        }
-    }
-
-    // ---------------- arrow row (perm row 0 = original row D): G'[0][j] = sum_c w0_c f_c conj(V[j][c])
-    for (int rp = tid; rp < 2 * Dp; rp += BR_THREADS) {
-        float a = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < n; ++c) a = fmaf(w0f[c], VTl[c * VP + rp], a);
-        rowb[rp] = a;
-    }
-    __syncthreads();
-    for (int o = tid; o < D; o += BR_THREADS) {
-        const float gr = rowb[o], gim = -rowb[Dp + o];     // G[D][o]
-        Gb[(int64_t)D * n + o] = make_float2(gr, gim);
-        Gb[(int64_t)o * n + D] = make_float2(gr, -gim);
-        const float2 p = phi[b * D + o];                   // C[D][o] = conj(phi_o)
-        const float dr = gr - p.x, di = gim + p.y;
-        acc2 += 2.f * (dr * dr + di * di);
-    }
-    if (wave == 0) {   // corner: G'[0][0] = sum_c f_c w0_c^2
-        float g00 = 0.f;
-        for (int c = lane; c < n; c += 64) g00 = fmaf(w0f[c], z0s[c], g00);
-        g00 = wave_sum(g00);
-        if (lane == 0) {
-            Gb[(int64_t)D * n + D] = make_float2(g00, 0.f);
-            const float d = g00 - lw[S_CORNER_Z];
-            acc2 += d * d;
-        }
-    }
-    acc2 = wave_sum(acc2);
-    if (lane == 0) redb[wave] = acc2;
-    __syncthreads();
-    if (tid == 0) {
-        float s = 0.f;
-        for (int i = 0; i < BR_THREADS / 64; ++i) s += redb[i];
-        rn[b] = sqrtf(s);
-    }
+    rebuild_from_lds(g, b, lw, VTl, fs, w0f, z0s, rowb, redb, phi, h, G, rn, mark);
 }
 
 bool back_rebuild_supported(int D) { return D >= 1 && D <= 128; }
@@ -264,12 +203,31 @@ int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, c
         return ADMMNET_E_ARG;
     }
     const BrGeom g(D);
-    const size_t lds = g.lds_bytes();
-    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(back_rebuild_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(back_rebuild_kernel, dim3((unsigned)nb), dim3(BR_THREADS), lds, st, D, lw, ws.Wdc, ws.QV,
-                       ws.w, ws.w0, phi, h, G, rn);
+    const size_t lds = br_lds_bytes(g);
+    const int nct = (D + 1 + 31) / 32;
+    auto kern = nct == 1 ? back_rebuild_kernel<1, 0> : nct == 2 ? back_rebuild_kernel<2, 0>
+              : nct == 3 ? back_rebuild_kernel<3, 0> : nct == 4 ? back_rebuild_kernel<4, 0>
+              : D == 128 ? back_rebuild_kernel<5, 8> : back_rebuild_kernel<5, 0>;
+    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    static const bool timing = getenv("ADMMNET_BR_TIMING") != nullptr;   // developer aid, never on by default
+    unsigned long long *ptime = nullptr;
+    if (timing) {
+        ADMM_HIP(hipMalloc(&ptime, 16 * sizeof(unsigned long long)));
+        ADMM_HIP(hipMemsetAsync(ptime, 0, 16 * sizeof(unsigned long long), st));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(BR_THREADS), lds, st, D, lw, ws.Wdc, ws.QV,
+                       ws.w, ws.w0, phi, h, G, rn, ptime);
     ADMM_HIP(hipGetLastError());
+    if (timing) {
+        unsigned long long hb[16];
+        ADMM_HIP(hipMemcpyAsync(hb, ptime, sizeof(hb), hipMemcpyDeviceToHost, st));
+        ADMM_HIP(hipStreamSynchronize(st));
+        ADMM_HIP(hipFree(ptime));
+        static const char *nm[6] = {"eig map", "first slab", "phase A", "phase B", "phase C", "arrow+norm"};
+        fprintf(stderr, "[back_rebuild timing] D=%d nb=%lld  mean cycles per workgroup:\n", D, (long long)nb);
+        for (int i = 0; i < 6; ++i) fprintf(stderr, "   %-12s %10.0f\n", nm[i], (double)hb[i] / (double)nb);
+    }
     const int n = D + 1;
     if (w_out) ADMM_HIP(hipMemcpyAsync(w_out, ws.w, sizeof(float) * nb * n, hipMemcpyDeviceToDevice, st));
     return ADMMNET_OK;

@@ -110,7 +110,8 @@ int64_t pick_chunk(const admmnet_cfg *cfg, int64_t B);
 // ---- kernel launchers (each enqueues on `st`, returns ADMMNET_* code) ----------
 // prep.hip
 int launch_prep(const admmnet_cfg *cfg, const float *lw, int k, const float2 *y, const float2 *b,
-                const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st);
+                const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st,
+                bool no_matrix = false);
 int launch_build_generic(int n, int64_t nb, const float2 *A, const Ws &ws, hipStream_t st);
 int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const float2 *phi, const float *h,
                        const float2 *Z, const Ws &ws, hipStream_t st);
@@ -125,6 +126,9 @@ int launch_rotapply(int D, int64_t nb, const Ws &ws, hipStream_t st);
 // rebuild.hip
 int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st);     // dc.hip
 int launch_vgemm(int D, int64_t nb, const Ws &ws, hipStream_t st);                       // dc.hip
+bool arrow_rebuild_supported(int D);                                                       // arrow.hip
+int launch_arrow_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G, float *rn,
+                         float *w_out, int32_t *status, hipStream_t st);                  // arrow.hip
 bool back_rebuild_supported(int D);                                                        // backrebuild.hip
 int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G,
                         float *rn, float *w_out, const Ws &ws, hipStream_t st);           // backrebuild.hip

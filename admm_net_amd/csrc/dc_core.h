@@ -228,6 +228,21 @@ HD void deflate_scan_tol(int nn, float rho, float dmax, float zmax, FA ds, FA zs
     nrot_out = nrot;
 }
 
+// Fast path of the scan: does ANY deflation trigger at sorted position p?  When no position says yes
+// the serial scan would keep every entry (its running pj is always p - 1), so the caller may skip it and
+// copy (ds, zs) -> (dl, zl), src = identity, k = nn, nrot = 0 in parallel.  Same tests, same tolerance.
+template <class FA>
+HD bool deflate_triggers(int p, float rho, float dmax, float zmax, FA ds, FA zs) {
+    const float tol = 8.0f * kEps32 * fmaxf(dmax, zmax);
+    const float zj = zs[p];
+    if (rho * fabsf(zj) <= tol) return true;
+    if (p == 0) return false;
+    const float zpj = zs[p - 1];
+    const float q = zj * zj + zpj * zpj;
+    const float t = ds[p] - ds[p - 1];
+    return (fabsf(t * zj * zpj) <= tol * q) && !(q < 1e-30f);
+}
+
 template <class FA, class IA, class RA>
 HD void deflate_scan(int nn, float rho, FA ds, FA zs, FA dl, FA zl, IA src, RA rot, int &k_out, int &nrot_out) {
     float dmax = 0.f, zmax = 0.f;

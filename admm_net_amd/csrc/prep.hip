@@ -45,6 +45,7 @@ __device__ __forceinline__ float pr_block_reduce(float v, float *scr, bool is_ma
 constexpr int PM_FIRST = 1;      // layer 0: G = Z = 0, nothing is read
 constexpr int PM_ZZERO = 2;      // layer 1: stored Z is still zero (never written)
 constexpr int PM_PHI_ONLY = 4;   // last layer: only phi is needed (admm_net.py:757-764)
+constexpr int PM_NO_MATRIX = 8;  // layer 0 on the arrowhead path (arrow.hip): phi and h only, A is never formed
 
 __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
     int D, int mode, const float *__restrict__ lw, const float *__restrict__ lw_prev,
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
     }
     __syncthreads();
 
+    if (mode & PM_NO_MATRIX) return;
     // ---- stream the matrix: finish the lazy Z update, build A (arrow-first order)
     const float corner_g = lw[S_CORNER_G], inv_rho_g = lw[S_INV_RHO_G];
     const float corner_zp = first ? 0.f : lw_prev[S_CORNER_Z];
@@ -222,7 +224,8 @@ int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const flo
 }
 
 int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2 *y, const float2 *b,
-                const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st) {
+                const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st,
+                bool no_matrix) {
     ProfScope _prof(KC_PREP, st);
     if (nb <= 0) return ADMMNET_OK;
     const int D = cfg->M * cfg->N, n = D + 1;
@@ -233,6 +236,7 @@ int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2
     if (k == 0) mode |= PM_FIRST;
     if (k == 1) mode |= PM_ZZERO;
     if (phi_only) mode |= PM_PHI_ONLY;
+    if (no_matrix && k == 0) mode |= PM_NO_MATRIX;
     const int cur = k & 1, prv = cur ^ 1;
     const size_t lds = sizeof(float2) * 2 * D + sizeof(float) * (3 * D + kHid + 8);
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)nb), dim3(PR_THREADS), lds, st, D, mode, lw, lwp,

@@ -256,6 +256,9 @@ int launch_tridiag(int D, int64_t nb, const Ws &ws, hipStream_t st) {
     if (nb <= 0) return ADMMNET_OK;
     // D <= 128: register-resident kernel (tridiag_reg.hip).  ADMMNET_TRIDIAG=lds keeps the
     // LDS-resident version below selectable for A/B runs; it also serves 128 < D <= 256 (global image).
+    // (A 512-thread, 4-waves-per-SIMD variant of tridiag_reg was measured 1.6x SLOWER: the O(n) per-wave
+    // work of every reflector -- norm, Householder scalars, vector set-up, reductions -- is replicated in
+    // each wave, and with 8 waves per matrix it outweighs the better latency hiding.)
     static int use_lds = -1;
     if (use_lds < 0) {
         const char *e = getenv("ADMMNET_TRIDIAG");

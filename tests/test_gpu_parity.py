@@ -98,6 +98,36 @@ def test_glayer_block_vs_oracle(dev):
         assert rel(rn.cpu().numpy(), t["rn"].numpy()) < 1e-5
 
 
+def test_glayer_first_layer_arrowhead_edge_cases(dev):
+    """Layer 0 (Z = 0) runs the direct arrowhead eigensolver (arrow.hip): repeated h (rotation deflation),
+    zero phi entries (trivial deflation), all-equal h, strong coupling -- against the oracle's G-layer in f64."""
+    z, m, sd, (Nb, Nd, K, B, L, head, _) = load_case(os.path.join(ROOT, "tests/golden/phiest_8x16_K3_perturbed.npz"))
+    D = Nb * Nd
+    rng = np.random.default_rng(17)
+    phis, hs = [], []
+    for case in range(6):
+        h = rng.uniform(0.05, 1.0, D)
+        p = (rng.standard_normal(D) + 1j * rng.standard_normal(D)) * 0.1
+        if case == 1: h = np.round(h, 2)
+        if case == 2: p[::3] = 0
+        if case == 3: h[:] = 0.37
+        if case == 4: p *= 40
+        if case == 5: h = np.sort(h); h[10:30] = h[10]; p[50:70] *= 1e-7
+        phis.append(p); hs.append(h)
+    phi = torch.from_numpy(np.stack(phis)).to(torch.complex128)
+    h = torch.from_numpy(np.stack(hs)).to(torch.float64)
+    sd64 = {k_: (v.double() if v.is_floating_point() else v) for k_, v in sd.items()}
+    Zero = torch.zeros(phi.shape[0], D + 1, D + 1, dtype=torch.complex128)
+    Gref, wref, _ = R.g_layer(sd64, 0, phi, h, Zero, return_eig=True)
+    G, w, rn = ops.glayer(m, 0, phi.to(torch.complex64).to(dev), h.float().to(dev), None)
+    G = G.cpu().numpy()
+    assert rel(G, Gref.numpy()) < 2e-5
+    assert np.array_equal(G, G.conj().transpose(0, 2, 1))
+    assert rel(np.sort(w.cpu().numpy(), 1), wref.numpy()) < 1e-5
+    _, rn_ref, _ = R.z_layer(sd64, 0, phi, h, Gref, Zero, return_aux=True)   # residual norm of the Z-layer (its own corner)
+    assert rel(rn.cpu().numpy(), rn_ref.numpy()) < 2e-5
+
+
 # ------------------------------------------------------------------ whole forward vs the reference
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
 def test_forward_matches_reference_fixture(dev, path):

@@ -335,3 +335,53 @@ def test_dc_model(dc_model, name):
     assert np.abs(W.T @ W - np.eye(n)).max() < 6e-6
     assert np.abs(lam - np.linalg.eigvalsh(T)).max() < 2e-6 * scale
     assert st[3] <= 25   # middle-way iteration: a handful of passes per root, bisection fallbacks are rare
+
+
+# ---------------------------------------------------------------- host model of the arrowhead eigensolver (first G-layer)
+@pytest.fixture(scope="module")
+def arrow_model():
+    so = os.path.join(ROOT, "tests", "host_model", "libarrow_model.so")
+    src = os.path.join(ROOT, "tests", "host_model", "arrow_model.cpp")
+    cores = [os.path.join(ROOT, "admm_net_amd", "csrc", f) for f in ("arrow_core.h", "dc_core.h", "eig_core.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + cores):
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-I", os.path.dirname(cores[0]), src, "-o", so])
+    lib = ctypes.CDLL(so)
+    lib.arrow_solve.argtypes = [ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 5
+    return lib
+
+
+def arrow_cases():
+    """(alpha, z, h) triples: plain, repeated h (type-2 deflation), zero arrow entries (type-1), all-equal h,
+    tiny sizes, strong coupling, wide dynamic range."""
+    rng = np.random.default_rng(3)
+    out = {}
+    for name, D in [("plain128", 128), ("repeated128", 128), ("zeros128", 128), ("equal128", 128), ("d3", 3), ("d1", 1),
+                    ("d256", 256), ("strong128", 128), ("mixed100", 100)]:
+        h = rng.uniform(0.1, 1.0, D)
+        z = (rng.standard_normal(D) + 1j * rng.standard_normal(D)) * 0.1
+        alpha = 2.5
+        if name.startswith("repeated"): h = np.round(h, 2)
+        if name.startswith("zeros"): z[::3] = 0
+        if name.startswith("equal"): h[:] = 0.5
+        if name.startswith("strong"): alpha, z = -3.0, z * 30
+        if name.startswith("mixed"):
+            h = np.sort(h); h[10:20] = h[10]; z[40:60] *= 1e-6; z *= 10.0; alpha = -0.7
+        out[name] = (alpha, z.astype(np.complex64), h.astype(np.float32))
+    return out
+
+
+@pytest.mark.parametrize("name", list(arrow_cases().keys()))
+def test_arrow_model(arrow_model, name):
+    """Arrowhead eigensolver cores (arrow_core.h) run sequentially on the CPU against numpy eigh in float64."""
+    alpha, z, h = arrow_cases()[name]
+    D = len(h); n = D + 1
+    lam = np.zeros(n, np.float32); V = np.zeros((n, n), np.complex64); st = (ctypes.c_int * 4)()
+    assert arrow_model.arrow_solve(D, alpha, z.ctypes.data, h.ctypes.data, lam.ctypes.data, V.ctypes.data, st) == 0
+    A = np.zeros((n, n), np.complex128)
+    A[0, 0] = alpha; A[0, 1:] = z.conj(); A[1:, 0] = z; A[1:, 1:] = np.diag(h.astype(np.float64))
+    sc = np.abs(A).max()
+    assert np.all(np.diff(lam) >= 0)
+    assert np.abs(A @ V - V * lam).max() < 4e-6 * sc
+    assert np.abs(V.conj().T @ V - np.eye(n)).max() < 6e-6
+    assert np.abs(lam - np.linalg.eigvalsh(A)).max() < 2e-6 * sc
+    assert st[3] <= 30   # secular iterations per root
