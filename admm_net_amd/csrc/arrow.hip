@@ -74,6 +74,7 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
     float *zh = tau + NP;
     float *vals = zh + NP;
     float *x0 = vals + NP;
+    float *lamd = zs;   // (after the deflation scan) d[org_j]: origin pole value of root j
     int *perm = reinterpret_cast<int *>(x0 + NP);
     int *src = perm + NP;
     int *org = src + NP;
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
     for (int i = tid; i < D; i += AR_THREADS) {
         const float v = hraw[i];
         int r = 0;
+#pragma unroll 8
         for (int q = 0; q < D; ++q) {
             const float u = hraw[q];
             r += (u < v) || (u == v && q < i);
@@ -160,16 +162,18 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
             arrow_root(k, j, alpha, znorm, dl, zl, o, t);
             org[j] = o;
             tau[j] = t;
+            lamd[j] = dl[o];
             vals[j] = dl[o] + t;
         }
     }
     __syncthreads();
     mark(1);
     // ---- P5: zeta-hat, final (ascending, stable) positions of all n eigenvalues
-    for (int i = tid; i < k; i += AR_THREADS) zh[i] = arrow_zhat(k, i, dl, org, tau);
+    for (int i = tid; i < k; i += AR_THREADS) zh[i] = arrow_zhat(k, i, dl, lamd, tau);
     for (int s = tid; s < n; s += AR_THREADS) {
         const float v = vals[s];
         int r = 0;
+#pragma unroll 8
         for (int q = 0; q < n; ++q) {
             const float u = vals[q];
             r += (u < v) || (u == v && q < s);
@@ -187,7 +191,8 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
             if (s <= k) {
                 float nrm = 1.f;
                 if (k > 0) {
-                    const float dorg = dl[org[s]], ts = tau[s];
+                    const float dorg = lamd[s], ts = tau[s];
+#pragma unroll 4
                     for (int i = 0; i < k; ++i) {
                         const float v = fdiv_fast(zh[i], (dorg - dl[i]) + ts);   // zhat_i / (lam_s - d_i)
                         nrm = fmaf(v, v, nrm);
@@ -229,13 +234,15 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
         const int kd = kidx[ipos[i]];
         if (kd >= 0) {   // surviving pole kd: component zhat x0_s / (lam_s - d) in every root's eigenvector
             const float zi = zh[kd], di = dl[kd];
+#pragma unroll 4
             for (int s = 0; s <= k; ++s) {
-                const float v = fdiv_fast(zi, (dl[org[s]] - di) + tau[s]) * x0[s];
+                const float v = fdiv_fast(zi, (lamd[s] - di) + tau[s]) * x0[s];
                 colr[rnk[s] * VP] = v;
             }
             for (int s = k + 1; s < n; ++s) colr[rnk[s] * VP] = 0.f;
         } else {         // deflated pole: unit vector of slot -(kd) - 1
             const int slot = -kd - 1;
+#pragma unroll 4
             for (int s = 0; s < n; ++s) colr[rnk[s] * VP] = (s == slot) ? 1.f : 0.f;
         }
     }
@@ -256,6 +263,7 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
     for (int i = tid; i < D; i += AR_THREADS) {
         float *colr = VTl + i, *coli = VTl + Dp + i;
         const float pr = phr[i], pi = phim[i];
+#pragma unroll 8
         for (int c = 0; c < n; ++c) {
             const float x = colr[c * VP];
             colr[c * VP] = x * pr;

@@ -30,6 +30,8 @@ struct ArrowEval {
 template <class DA, class ZA>
 HD ArrowEval arrow_eval(int k, int jsplit, float c0, float dorg, float t, DA d, ZA z) {
     float sum = 0.f, asum = 0.f, dall = 0.f, dps = 0.f;
+    // (unrolled: one LDS round trip per iteration would otherwise bound the loop, not the arithmetic)
+#pragma unroll 4
     for (int i = 0; i < k; ++i) {
         const float del = (d(i) - dorg) - t;
         const float r = fdiv_fast(1.0f, del);
@@ -143,37 +145,39 @@ HD void arrow_root_upper(int k, int j, float alpha, float znorm, DA d, ZA z, int
 }
 
 // Root j of k + 1 (0 <= j <= k) of the arrowhead (alpha; d[k] ascending distinct; z[k] > 0).
+// The bottom root is minus the top root of the reflected problem (-alpha, -d reversed); both cases run
+// through the SAME code with a per-lane (sign, index map), so a wave whose lanes hold different roots
+// does not execute the solver twice.
 template <class FA>
 HD void arrow_root(int k, int j, float alpha, float znorm, FA d, FA z, int &org_out, float &tau_out,
                    int *nit = nullptr) {
-    if (j > 0) {
-        arrow_root_upper(k, j, alpha, znorm, [&](int i) { return d[i]; }, [&](int i) { return z[i]; }, org_out,
-                         tau_out, nit);
-        return;
-    }
-    // bottom root = -(top root of the reflected problem  -alpha, -d reversed)
+    const bool refl = (j == 0);
+    const float sg = refl ? -1.0f : 1.0f;
+    const int km1 = k - 1;
     int orgr;
     float taur;
-    arrow_root_upper(k, k, -alpha, znorm, [&](int i) { return -d[k - 1 - i]; }, [&](int i) { return z[k - 1 - i]; },
-                     orgr, taur, nit);
-    org_out = k - 1 - orgr;
-    tau_out = -taur;
+    arrow_root_upper(k, refl ? k : j, sg * alpha, znorm, [&](int i) { return sg * d[refl ? km1 - i : i]; },
+                     [&](int i) { return z[refl ? km1 - i : i]; }, orgr, taur, nit);
+    org_out = refl ? km1 - orgr : orgr;
+    tau_out = sg * taur;
 }
 
-// d_i - lam_j from the stored (org_j, tau_j), roots j = 0..k
-template <class FA, class IA>
-HD float arrow_delta(FA d, IA org, FA tau, int i, int j) {
-    return (d[i] - d[org[j]]) - tau[j];
+// d_i - lam_j from the stored origin value lamd_j = d[org_j] and tau_j, roots j = 0..k
+template <class FA>
+HD float arrow_delta(FA d, FA lamd, FA tau, int i, int j) {
+    return (d[i] - lamd[j]) - tau[j];
 }
 
 // Gu / Eisenstat zeta-hat_i (>= 0) from the computed roots
-template <class FA, class IA>
-HD float arrow_zhat(int k, int i, FA d, IA org, FA tau) {
-    float w = arrow_delta(d, org, tau, i, i) * (-arrow_delta(d, org, tau, i, i + 1));   // (d_i - lam_i)(lam_{i+1} - d_i)
+template <class FA>
+HD float arrow_zhat(int k, int i, FA d, FA lamd, FA tau) {
+    const float di = d[i];
+    float w = ((di - lamd[i]) - tau[i]) * -((di - lamd[i + 1]) - tau[i + 1]);   // (d_i - lam_i)(lam_{i+1} - d_i)
+#pragma unroll 4
     for (int j = 0; j < k; ++j) {
-        if (j == i) continue;
         const int jr = (j < i) ? j : j + 1;   // root paired with pole j
-        w *= fdiv_fast(arrow_delta(d, org, tau, i, jr), d[i] - d[j]);
+        const float q = fdiv_fast((di - lamd[jr]) - tau[jr], di - d[j]);
+        w *= (j == i) ? 1.0f : q;
     }
     return sqrtf(fabsf(w));
 }

@@ -182,9 +182,11 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                 int r;
                 if (i < n1) {
                     r = i;
+#pragma unroll 4
                     for (int q = n1; q < nn; ++q) r += (lam[a + q] < v);
                 } else {
                     r = i - n1;
+#pragma unroll 4
                     for (int q = 0; q < n1; ++q) r += (lam[a + q] <= v);
                 }
                 perm[a + r] = i;
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
             for (int p = tl; p < nn; p += ts) {
                 const float v = vals[a + p];
                 int r = 0;
+#pragma unroll 4
                 for (int q = 0; q < nn; ++q) {
                     const float u = vals[a + q];
                     r += (u < v) || (u == v && q < p);
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
             for (int j = tl; j < k; j += ts) {
                 float nrm = 0.f;
                 const float dorg = dl[a + org[a + j]], tj = tau[a + j];
+#pragma unroll 4
                 for (int i = 0; i < k; ++i) {
                     const float u = fdiv_fast(zh[a + i], (dl[a + i] - dorg) - tj);
                     nrm = fmaf(u, u, nrm);

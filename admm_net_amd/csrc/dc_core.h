@@ -274,6 +274,8 @@ template <class FA>
 HD SecEval secular_eval(int k, int jsplit, float rhoinv, float dorg, float t, FA d, FA z) {
     // psi: poles 0..jsplit, phi: the rest
     float sum = 0.f, asum = 0.f, dall = 0.f, dps = 0.f;
+    // (unrolled: one LDS round trip per iteration would otherwise bound the loop, not the arithmetic)
+#pragma unroll 4
     for (int i = 0; i < k; ++i) {
         const float del = (d[i] - dorg) - t;
         const float r = fdiv_fast(1.0f, del);
@@ -384,9 +386,10 @@ HD float dc_delta(FA d, IA org, FA tau, int i, int j) {
 template <class FA, class IA>
 HD float lowner_zhat(int k, int i, FA d, FA z, IA org, FA tau) {
     float w = dc_delta(d, org, tau, i, i);   // d_i - lam_i
+#pragma unroll 4
     for (int j = 0; j < k; ++j) {
-        if (j == i) continue;
-        w *= fdiv_fast(dc_delta(d, org, tau, i, j), d[i] - d[j]);
+        const float q = fdiv_fast(dc_delta(d, org, tau, i, j), d[i] - d[j]);
+        w *= (j == i) ? 1.0f : q;
     }
     const float r = sqrtf(fabsf(w));
     return z[i] >= 0.f ? r : -r;

@@ -60,6 +60,26 @@ __device__ __forceinline__ v2 pk_cmacc(v2 acc, v2 a, v2 aj, v2 b) {
     acc = __builtin_elementwise_fma(b.xx, a, acc);
     return __builtin_elementwise_fma(b.yy, aj, acc);
 }
+// The same two products with the i * v / -i * a rotations folded into the operand selects and negate
+// bits of v_pk_fma_f32 (the compiler materialises the rotated pair with a v_mov + v_xor per use):
+//   acc + m * v        = fma(m.xx, (v.x, v.y), acc), then fma(m.yy, (-v.y, v.x), .)
+//   acc + a * conj(b)  = fma(b.xx, (a.x, a.y), acc), then fma(b.yy, (a.y, -a.x), .)
+// The hazard recogniser does not see inside inline asm: a value that a DPP / lane instruction reads next
+// must come out of a compiler-emitted VALU op (see the last term of the HEMV loops).
+__device__ __forceinline__ v2 pk_cmac_sel(v2 acc, v2 m, v2 v) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "+v"(acc)
+        : "v"(m), "v"(v));
+    return acc;
+}
+__device__ __forceinline__ v2 pk_cmacc_sel(v2 acc, v2 a, v2 b) {
+    asm("v_pk_fma_f32 %0, %2, %1, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
+        : "+v"(acc)
+        : "v"(a), "v"(b));
+    return acc;
+}
 // stage-wise row reduction of NA complex values: the NA chains interleave, so no DPP hazard stalls
 template <int NA, int A0>
 __device__ __forceinline__ void row16_sum_all(v2 (&acc)[NA]) {
@@ -148,7 +168,7 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
     }
     if (tr == 0.f && tim == 0.f) return;   // H = I (uniform)
 
-    v2 vr[NA], vc[NA], vcj[NA];
+    v2 vr[NA], vc[NA];
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
         vr[a] = pk_cmac(v2{0.f, 0.f}, tov2(col[16 * a + ti]), scv, scj);
@@ -157,8 +177,8 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
             if (16 * a + ti == u) vr[a] = v2{1.f, 0.f};
             if (16 * a + tj == u) vc[a] = v2{1.f, 0.f};
         }
-        vcj[a] = rot(vc[a]);
     }
+    const v2 vcj = rot(vc[NA - 1]);
     // p = tau * M v : partial over my columns, summed along the 16 fast lanes (all lanes of a row
     // of the thread grid end up with the p of their matrix rows)
     v2 pr[NA];
@@ -166,8 +186,8 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
     for (int a = A0; a < NA; ++a) {
         v2 acc = {0.f, 0.f};
 #pragma unroll
-        for (int b = A0; b < NA; ++b) acc = pk_cmac(acc, tov2(m[a][b]), vc[b], vcj[b]);
-        pr[a] = acc;
+        for (int b = A0; b < NA - 1; ++b) acc = pk_cmac_sel(acc, tov2(m[a][b]), vc[b]);
+        pr[a] = pk_cmac(acc, tov2(m[a][NA - 1]), vc[NA - 1], vcj);   // last term by the compiler (DPP reads pr next)
     }
     row16_sum_all<NA, A0>(pr);
     const v2 tauv = tov2(tau), tauj = rot(tauv);
@@ -211,12 +231,11 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
         if (a == A0) w = (i >= u) ? w : v2{0.f, 0.f};
         const v2 wra = -w;
         const v2 vra = -vr[a];
-        const v2 wraj = rotc(wra), vraj = rotc(vra);
 #pragma unroll
         for (int b = A0; b < NA; ++b) {
             v2 x = tov2(m[a][b]);
-            x = pk_cmacc(x, vra, vraj, wc[b]);
-            x = pk_cmacc(x, wra, wraj, vc[b]);
+            x = pk_cmacc_sel(x, vra, wc[b]);
+            x = pk_cmacc_sel(x, wra, vc[b]);
             if (a == b && ti == tj) x.y = 0.f;
             m[a][b] = tof2(x);
         }
@@ -251,26 +270,24 @@ __device__ __forceinline__ void q_step(float2 (&m)[NA][NA], const TrShared<NA> &
     q_load<NA, AP, FULL>(vn, u - 1, D, Mg);
     const float2 tau = sh.taus[u];
     if (!(tau.x == 0.f && tau.y == 0.f)) {
-        v2 vc[NA], vj[NA], y[NA];
+        v2 vc[NA], y[NA];
 #pragma unroll
-        for (int b = A0; b < NA; ++b) {
-            vc[b] = tov2(vcs[b]);
-            vj[b] = rot(vc[b]);
-        }
+        for (int b = A0; b < NA; ++b) vc[b] = tov2(vcs[b]);
+        const v2 vjl = rot(vc[NA - 1]);
 #pragma unroll
         for (int a = A0; a < NA; ++a) {
             v2 acc = {0.f, 0.f};
 #pragma unroll
-            for (int b = A0; b < NA; ++b) acc = pk_cmac(acc, tov2(m[a][b]), vc[b], vj[b]);
-            y[a] = acc;
+            for (int b = A0; b < NA - 1; ++b) acc = pk_cmac_sel(acc, tov2(m[a][b]), vc[b]);
+            y[a] = pk_cmac(acc, tov2(m[a][NA - 1]), vc[NA - 1], vjl);   // last term by the compiler (DPP reads y next)
         }
         row16_sum_all<NA, A0>(y);
         const v2 nct = v2{-tau.x, tau.y}, nctj = rot(nct);   // -conj(tau)
 #pragma unroll
         for (int a = A0; a < NA; ++a) {
-            const v2 nty = pk_cmac(v2{0.f, 0.f}, y[a], nct, nctj), ntyj = rotc(nty);
+            const v2 nty = pk_cmac(v2{0.f, 0.f}, y[a], nct, nctj);
 #pragma unroll
-            for (int b = A0; b < NA; ++b) m[a][b] = tof2(pk_cmacc(tov2(m[a][b]), nty, ntyj, vc[b]));   // -= conj(tau) y conj(v_b)
+            for (int b = A0; b < NA; ++b) m[a][b] = tof2(pk_cmacc_sel(tov2(m[a][b]), nty, vc[b]));   // -= conj(tau) y conj(v_b)
         }
     }
 #pragma unroll

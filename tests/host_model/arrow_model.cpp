@@ -48,7 +48,7 @@ int arrow_solve(int D, float alpha, const float *z_ri, const float *h, float *la
     deflate_scan_tol(D, 1.0f, dmax, zmax, ds.data(), zs.data(), dl.data(), zl.data(), src.data(), rot.data(), k, nrot);
     // roots
     std::vector<int> org(k + 1);
-    std::vector<float> tau(k + 1), vals(n);
+    std::vector<float> tau(k + 1), lamd(k + 1), vals(n);
     float zn2 = 0.f;
     for (int i = 0; i < k; ++i) zn2 += zl[i] * zl[i];
     const float znorm = std::sqrt(zn2);
@@ -60,17 +60,18 @@ int arrow_solve(int D, float alpha, const float *z_ri, const float *h, float *la
             int nit = 0;
             arrow_root(k, j, alpha, znorm, dl.data(), zl.data(), org[j], tau[j], &nit);
             itmax = std::max(itmax, nit);
-            vals[j] = dl[org[j]] + tau[j];
+            lamd[j] = dl[org[j]];
+            vals[j] = lamd[j] + tau[j];
         }
     }
     for (int p = k; p < D; ++p) vals[p + 1] = dl[p];
     // zeta-hat, norms
     std::vector<float> zh(k), x0(k + 1, 1.f);
-    for (int i = 0; i < k; ++i) zh[i] = arrow_zhat(k, i, dl.data(), org.data(), tau.data());
+    for (int i = 0; i < k; ++i) zh[i] = arrow_zhat(k, i, dl.data(), lamd.data(), tau.data());
     for (int j = 0; j <= k && k > 0; ++j) {
         float nrm = 1.f;
         for (int i = 0; i < k; ++i) {
-            const float v = zh[i] / (-arrow_delta(dl.data(), org.data(), tau.data(), i, j));
+            const float v = zh[i] / (-arrow_delta(dl.data(), lamd.data(), tau.data(), i, j));
             nrm += v * v;
         }
         x0[j] = 1.0f / std::sqrt(nrm);
@@ -87,7 +88,7 @@ int arrow_solve(int D, float alpha, const float *z_ri, const float *h, float *la
     for (int j = 0; j <= k; ++j) {
         X[(size_t)0 * n + j] = x0[j];
         for (int i = 0; i < k; ++i)
-            X[(size_t)(1 + src[i]) * n + j] = zh[i] * x0[j] / (-arrow_delta(dl.data(), org.data(), tau.data(), i, j));
+            X[(size_t)(1 + src[i]) * n + j] = zh[i] * x0[j] / (-arrow_delta(dl.data(), lamd.data(), tau.data(), i, j));
     }
     for (int p = k; p < D; ++p) X[(size_t)(1 + src[p]) * n + (p + 1)] = 1.f;
     // undo the deflation rotations (reverse order): v = G^T v'
