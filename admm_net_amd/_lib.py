@@ -51,6 +51,10 @@ SYMBOLS = {
     "admmnet_spectrum_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     "admmnet_spectrum_f64": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p,
                                        c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "admmnet_peak_search_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int64]),
+    "admmnet_peak_search_f64": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32,
+                                          c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64,
+                                          c_void_p]),
     "admmnet_profile_enable": (c_int32, [c_int32]),
     "admmnet_profile_read": (c_int32, [c_void_p, c_void_p, c_int32]),
 }

@@ -555,4 +555,33 @@ int admmnet_spectrum_f64(const void *phi, int64_t B, int32_t xbase, int32_t ybas
     return launch_spectrum_main((const float2 *)phi, B, xbase, ybase, tabD, nx, tabS, ny, out, st);
 }
 
+int64_t admmnet_peak_search_workspace_bytes(int32_t xbase, int32_t ybase, int32_t nx, int32_t ny, int64_t B) {
+    const int64_t t = admmnet_spectrum_workspace_bytes(xbase, ybase, nx, ny);
+    if (t < 0 || B < 1) return -1;
+    return align_up(t, 256) + align_up((int64_t)sizeof(double) * B * nx * ny, 256);
+}
+
+int admmnet_peak_search_f64(const void *phi, int64_t B, int32_t xbase, int32_t ybase, const double *axis_x,
+                            int32_t nx, const double *axis_y, int32_t ny, const double *opts7, int32_t iters,
+                            int32_t max_peaks, double *peaks, int32_t *counts, void *workspace,
+                            int64_t workspace_bytes, void *stream) {
+    const int64_t need = admmnet_peak_search_workspace_bytes(xbase, ybase, nx, ny, B);
+    if (need < 0 || !phi || !axis_x || !axis_y || !opts7 || !peaks || !counts || !workspace || nx < 1 || ny < 1 ||
+        iters < 0 || max_peaks < 1) {
+        set_error("peak search: bad argument");
+        return ADMMNET_E_ARG;
+    }
+    if (workspace_bytes < need) {
+        set_error("peak search: workspace too small");
+        return ADMMNET_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t tb = align_up(admmnet_spectrum_workspace_bytes(xbase, ybase, nx, ny), 256);
+    double *Z = (double *)((char *)workspace + tb);
+    int rc;
+    if ((rc = admmnet_spectrum_f64(phi, B, xbase, ybase, axis_x, nx, axis_y, ny, Z, workspace, tb, stream))) return rc;
+    return launch_peaks((const float2 *)phi, B, xbase, ybase, Z, nx, ny, axis_x, axis_y, opts7, iters, max_peaks,
+                        peaks, counts, st);
+}
+
 }  // extern "C"

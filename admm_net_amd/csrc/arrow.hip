@@ -156,14 +156,32 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
         if (tid == 0) vals[0] = alpha;
     } else {
         const float znorm = sh.znorm;
-        for (int j = tid; j <= k; j += AR_THREADS) {
-            int o;
-            float t;
-            arrow_root(k, j, alpha, znorm, dl, zl, o, t);
-            org[j] = o;
-            tau[j] = t;
-            lamd[j] = dl[o];
-            vals[j] = dl[o] + t;
+        if (2 * (k + 1) <= AR_THREADS) {   // two adjacent lanes per root: each sums every other pole
+            const int j = tid >> 1, sub = tid & 1;
+            if (j <= k) {
+                int o;
+                float t;
+                arrow_root(k, j, alpha, znorm, dl, zl, o, t, nullptr, sub, 2, [](float x) {
+                    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1,
+                                                                                       0xF, 0xF, false));   // quad_perm [1,0,3,2]
+                });
+                if (sub == 0) {
+                    org[j] = o;
+                    tau[j] = t;
+                    lamd[j] = dl[o];
+                    vals[j] = dl[o] + t;
+                }
+            }
+        } else {
+            for (int j = tid; j <= k; j += AR_THREADS) {
+                int o;
+                float t;
+                arrow_root(k, j, alpha, znorm, dl, zl, o, t);
+                org[j] = o;
+                tau[j] = t;
+                lamd[j] = dl[o];
+                vals[j] = dl[o] + t;
+            }
         }
     }
     __syncthreads();

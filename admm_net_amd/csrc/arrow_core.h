@@ -27,12 +27,20 @@ struct ArrowEval {
 
 // F at lam = d_org + t, split at pole index jsplit (psi: poles 0..jsplit, phi: the rest); `c0` = d_org - alpha.
 // DA / ZA are accessors (index -> value) so that the bottom root can run on the reflected problem.
-template <class DA, class ZA>
-HD ArrowEval arrow_eval(int k, int jsplit, float c0, float dorg, float t, DA d, ZA z) {
+// A root may be shared by a group of G adjacent lanes: lane `sub` sums the poles sub, sub + G, ... and `red`
+// adds the partial sums across the group (every lane of the group gets the same totals and then takes the
+// same decisions).  Host / single lane: sub = 0, G = 1, red = identity.
+struct ArrowNoReduce {
+    HD float operator()(float x) const { return x; }
+};
+
+template <class DA, class ZA, class Red = ArrowNoReduce>
+HD ArrowEval arrow_eval(int k, int jsplit, float c0, float dorg, float t, DA d, ZA z, int sub = 0, int G = 1,
+                        Red red = Red()) {
     float sum = 0.f, asum = 0.f, dall = 0.f, dps = 0.f;
     // (unrolled: one LDS round trip per iteration would otherwise bound the loop, not the arithmetic)
 #pragma unroll 4
-    for (int i = 0; i < k; ++i) {
+    for (int i = sub; i < k; i += G) {
         const float del = (d(i) - dorg) - t;
         const float r = fdiv_fast(1.0f, del);
         const float zi = z(i);
@@ -43,6 +51,10 @@ HD ArrowEval arrow_eval(int k, int jsplit, float c0, float dorg, float t, DA d, 
         dall += dterm;
         dps += (i <= jsplit) ? dterm : 0.f;
     }
+    sum = red(sum);
+    asum = red(asum);
+    dall = red(dall);
+    dps = red(dps);
     ArrowEval e;
     e.w = (c0 + t) + sum;
     e.dpsi = dps;
@@ -54,9 +66,9 @@ HD ArrowEval arrow_eval(int k, int jsplit, float c0, float dorg, float t, DA d, 
 // Root j (0 < j <= k) of the k-pole problem given through accessors; the caller maps j = 0 onto j = k of
 // the reflected problem.  j < k: interior root in (d_{j-1}, d_j); j = k: top root in (d_{k-1}, ub).
 // Returns the origin pole and tau (lam = d_org + tau), as secular_root does.
-template <class DA, class ZA>
+template <class DA, class ZA, class Red = ArrowNoReduce>
 HD void arrow_root_upper(int k, int j, float alpha, float znorm, DA d, ZA z, int &org_out, float &tau_out,
-                         int *nit = nullptr) {
+                         int *nit = nullptr, int sub = 0, int G = 1, Red red = Red()) {
     if (nit) *nit = 0;
     const bool top = (j == k);
     int org, plo, phi_;
@@ -78,7 +90,7 @@ HD void arrow_root_upper(int k, int j, float alpha, float znorm, DA d, ZA z, int
         }
         hi = hi * (1.0f + 8.0f * kEps32) + 1e-30f;
         t = hi;
-        e = arrow_eval(k, plo, d(org) - alpha, d(org), t, d, z);
+        e = arrow_eval(k, plo, d(org) - alpha, d(org), t, d, z, sub, G, red);
         if (e.w <= 0.f) {   // numerical corner: the root sits at the bound
             org_out = org;
             tau_out = hi;
@@ -88,7 +100,7 @@ HD void arrow_root_upper(int k, int j, float alpha, float znorm, DA d, ZA z, int
         plo = j - 1;
         phi_ = j;
         const float half = 0.5f * (d(j) - d(j - 1));
-        e = arrow_eval(k, plo, d(j - 1) - alpha, d(j - 1), half, d, z);
+        e = arrow_eval(k, plo, d(j - 1) - alpha, d(j - 1), half, d, z, sub, G, red);
         if (e.w >= 0.f) {   // root in the lower half: measure from d_{j-1}
             org = j - 1;
             lo = 0.f;
@@ -136,7 +148,7 @@ HD void arrow_root_upper(int k, int j, float alpha, float znorm, DA d, ZA z, int
         if (!(tn > lo && tn < hi)) tn = 0.5f * (lo + hi);
         if (tn == t || tn == lo || tn == hi) break;
         t = tn;
-        e = arrow_eval(k, plo, c0, dorg, t, d, z);
+        e = arrow_eval(k, plo, c0, dorg, t, d, z, sub, G, red);
     }
     if (t == 0.f) t = (lo == 0.f) ? 0.5f * hi : 0.5f * lo;
     if (t == 0.f) t = (lo == 0.f) ? 1e-30f : -1e-30f;
@@ -148,16 +160,16 @@ HD void arrow_root_upper(int k, int j, float alpha, float znorm, DA d, ZA z, int
 // The bottom root is minus the top root of the reflected problem (-alpha, -d reversed); both cases run
 // through the SAME code with a per-lane (sign, index map), so a wave whose lanes hold different roots
 // does not execute the solver twice.
-template <class FA>
+template <class FA, class Red = ArrowNoReduce>
 HD void arrow_root(int k, int j, float alpha, float znorm, FA d, FA z, int &org_out, float &tau_out,
-                   int *nit = nullptr) {
+                   int *nit = nullptr, int sub = 0, int G = 1, Red red = Red()) {
     const bool refl = (j == 0);
     const float sg = refl ? -1.0f : 1.0f;
     const int km1 = k - 1;
     int orgr;
     float taur;
     arrow_root_upper(k, refl ? k : j, sg * alpha, znorm, [&](int i) { return sg * d[refl ? km1 - i : i]; },
-                     [&](int i) { return z[refl ? km1 - i : i]; }, orgr, taur, nit);
+                     [&](int i) { return z[refl ? km1 - i : i]; }, orgr, taur, nit, sub, G, red);
     org_out = refl ? km1 - orgr : orgr;
     tau_out = sg * taur;
 }

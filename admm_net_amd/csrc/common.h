@@ -126,6 +126,9 @@ int launch_rotapply(int D, int64_t nb, const Ws &ws, hipStream_t st);
 // rebuild.hip
 int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st);     // dc.hip
 int launch_vgemm(int D, int64_t nb, const Ws &ws, hipStream_t st);                       // dc.hip
+int launch_peaks(const float2 *phi, int64_t B, int xbase, int ybase, const double *Z, int nx, int ny,
+                 const double *axis_x, const double *axis_y, const double *opt7, int iters, int max_peaks,
+                 double *peaks, int32_t *counts, hipStream_t st);                          // peaks.hip
 bool arrow_rebuild_supported(int D);                                                       // arrow.hip
 int launch_arrow_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G, float *rn,
                          float *w_out, int32_t *status, hipStream_t st);                  // arrow.hip

@@ -244,13 +244,25 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                     }
                 }
             }
-            for (int j = tl; j < k; j += ts) {
-                int o;
-                float t;
-                secular_root(k, j, rho, dl + a, zl + a, o, t);
-                org[a + j] = o;
-                tau[a + j] = t;
-                vals[a + j] = dl[a + o] + t;
+            {   // when the team has two lanes per root, adjacent lanes share one: each sums every other pole
+                // and one DPP swap adds the halves (one code path: G = 1 makes the swap a no-op)
+                const int G = (2 * k <= ts) ? 2 : 1;
+                const int sub = (G == 2) ? (tl & 1) : 0;
+                auto red = [G](float x) {
+                    const float y = __builtin_bit_cast(
+                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+                    return G == 2 ? x + y : x;
+                };
+                for (int j = (G == 2) ? (tl >> 1) : tl; j < k; j += ts / G) {
+                    int o;
+                    float t;
+                    secular_root(k, j, rho, dl + a, zl + a, o, t, nullptr, sub, G, red);
+                    if (sub == 0) {
+                        org[a + j] = o;
+                        tau[a + j] = t;
+                        vals[a + j] = dl[a + o] + t;
+                    }
+                }
             }
         }
         __syncthreads();

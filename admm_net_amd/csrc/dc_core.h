@@ -270,13 +270,21 @@ struct SecEval {
     float w, dpsi, dphi, err;
 };
 
-template <class FA>
-HD SecEval secular_eval(int k, int jsplit, float rhoinv, float dorg, float t, FA d, FA z) {
+// A root may be shared by a group of G adjacent lanes: lane `sub` sums the poles sub, sub + G, ... and `red`
+// adds the partial sums across the group (all lanes of the group then hold the same totals and take the same
+// decisions).  Host / single lane: sub = 0, G = 1, red = identity.
+struct SecNoReduce {
+    HD float operator()(float x) const { return x; }
+};
+
+template <class FA, class Red = SecNoReduce>
+HD SecEval secular_eval(int k, int jsplit, float rhoinv, float dorg, float t, FA d, FA z, int sub = 0, int G = 1,
+                        Red red = Red()) {
     // psi: poles 0..jsplit, phi: the rest
     float sum = 0.f, asum = 0.f, dall = 0.f, dps = 0.f;
     // (unrolled: one LDS round trip per iteration would otherwise bound the loop, not the arithmetic)
 #pragma unroll 4
-    for (int i = 0; i < k; ++i) {
+    for (int i = sub; i < k; i += G) {
         const float del = (d[i] - dorg) - t;
         const float r = fdiv_fast(1.0f, del);
         const float term = z[i] * z[i] * r;
@@ -286,6 +294,10 @@ HD SecEval secular_eval(int k, int jsplit, float rhoinv, float dorg, float t, FA
         dall += dterm;
         dps += (i <= jsplit) ? dterm : 0.f;
     }
+    sum = red(sum);
+    asum = red(asum);
+    dall = red(dall);
+    dps = red(dps);
     SecEval e;
     e.w = rhoinv + sum;
     e.dpsi = dps;
@@ -294,8 +306,9 @@ HD SecEval secular_eval(int k, int jsplit, float rhoinv, float dorg, float t, FA
     return e;
 }
 
-template <class FA>
-HD void secular_root(int k, int j, float rho, FA d, FA z, int &org_out, float &tau_out, int *nit = nullptr) {
+template <class FA, class Red = SecNoReduce>
+HD void secular_root(int k, int j, float rho, FA d, FA z, int &org_out, float &tau_out, int *nit = nullptr,
+                     int sub = 0, int G = 1, Red red = Red()) {
     if (nit) *nit = 0;
     if (k == 1) {
         org_out = 0;
@@ -315,11 +328,11 @@ HD void secular_root(int k, int j, float rho, FA d, FA z, int &org_out, float &t
         lo = 0.f;
         hi = rho;
         t = 0.5f * rho;
-        e = secular_eval(k, jsplit, rhoinv, d[org], t, d, z);
+        e = secular_eval(k, jsplit, rhoinv, d[org], t, d, z, sub, G, red);
     } else {
         const float gap = d[j + 1] - d[j];
         const float half = 0.5f * gap;
-        e = secular_eval(k, jsplit, rhoinv, d[j], half, d, z);
+        e = secular_eval(k, jsplit, rhoinv, d[j], half, d, z, sub, G, red);
         if (e.w >= 0.f) {   // root in the left half: measure from d_j
             org = j;
             lo = 0.f;
@@ -365,7 +378,7 @@ HD void secular_root(int k, int j, float rho, FA d, FA z, int &org_out, float &t
         if (!(tn > lo && tn < hi)) tn = 0.5f * (lo + hi);
         if (tn == t || tn == lo || tn == hi) break;           // bracket exhausted at this precision
         t = tn;
-        e = secular_eval(k, jsplit, rhoinv, dorg, t, d, z);
+        e = secular_eval(k, jsplit, rhoinv, dorg, t, d, z, sub, G, red);
     }
     // never return a pole itself (the Loewner products divide by these differences)
     if (t == 0.f) t = (lo == 0.f) ? 0.5f * hi : 0.5f * lo;

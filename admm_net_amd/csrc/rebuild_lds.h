@@ -73,27 +73,35 @@ __device__ __forceinline__ void rebuild_from_lds(const BrGeom &g, int64_t b, con
                 yi_[u] = row[Dp + j0];
             }
         };
+        auto mfma_group = [&](const float (&f_)[U], const float (&xr_)[U], const float (&xi_)[U],
+                              const float (&yr_)[U], const float (&yi_)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float ar = xr_[u] * f_[u], ai = xi_[u] * f_[u];
+                aRe = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, yr_[u], aRe, 0, 0, 0);
+                aIm = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, yr_[u], aIm, 0, 0, 0);
+                aRe = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, yi_[u], aRe, 0, 0, 0);
+                aIm = __builtin_amdgcn_mfma_f32_32x32x2f32(-ar, yi_[u], aIm, 0, 0, 0);
+            }
+        };
+        // two register sets in ping-pong, no copies; sched_barrier pins "next group's reads first, then this
+        // group's MFMAs" (left alone, the scheduler defers half of the reads to just before their use and
+        // drains the LDS queue at the end of every trip)
+        float fb[U], xrb[U], xib[U], yrb[U], yib[U];
+        const int ngrp = (nks + U - 1) / U;
         lds_group(0, fx, xr, xi, yr, yi);
-        for (int ks0 = 0; ks0 < nks; ks0 += U) {
-            float fn[U], xrn[U], xin[U], yrn[U], yin[U];
-            lds_group(ks0 + U, fn, xrn, xin, yrn, yin);   // (past the end: clamped, never used)
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float ar = xr[u] * fx[u], ai = xi[u] * fx[u];
-                aRe = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, yr[u], aRe, 0, 0, 0);
-                aIm = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, yr[u], aIm, 0, 0, 0);
-                aRe = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, yi[u], aRe, 0, 0, 0);
-                aIm = __builtin_amdgcn_mfma_f32_32x32x2f32(-ar, yi[u], aIm, 0, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                fx[u] = fn[u];
-                xr[u] = xrn[u];
-                xi[u] = xin[u];
-                yr[u] = yrn[u];
-                yi[u] = yin[u];
-            }
+        int gq = 0;
+        for (; gq + 1 < ngrp; gq += 2) {
+            lds_group((gq + 1) * U, fb, xrb, xib, yrb, yib);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(fx, xr, xi, yr, yi);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_group((gq + 2) * U, fx, xr, xi, yr, yi);   // (past the end: clamped, exact zeros, unused)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(fb, xrb, xib, yrb, yib);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (gq < ngrp) mfma_group(fx, xr, xi, yr, yi);
         // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {

@@ -105,3 +105,40 @@ def spectrum(phi: torch.Tensor, xbase: int, ybase: int, taus: torch.Tensor, fs: 
         _lib.check(lib.admmnet_spectrum_f64(_ptr(phi), B, xbase, ybase, _ptr(taus), nx, _ptr(fs), ny, _ptr(out),
                                             _ptr(ws), need, _stream(dev)), "admmnet_spectrum_f64")
     return out
+
+
+def peak_search(phi: torch.Tensor, xbase: int, ybase: int, opts=None, max_peaks: int = 256):
+    """alt_peak_search (utils/peakSearchUtils.py:63-173) for a whole batch on the device: coarse spectrum,
+    regional maxima and the refinement rounds, one signal per workgroup.
+
+    Returns (peaks [B, max_peaks, 3] float64 = (tau, f, height) in np.where order of the coarse maxima,
+    counts [B] int32 = number of regional maxima; rows >= counts[b] are zero, counts above max_peaks mean
+    the list was truncated).
+    """
+    from . import peak_search as ps
+    import ctypes as _ct
+    _need_cuda(phi, "phi")
+    lib = _lib.load()
+    dev = phi.device
+    B, D = phi.shape
+    if D != xbase * ybase:
+        raise ValueError(f"phi has {D} entries, expected xbase*ybase = {xbase * ybase}")
+    so = {**ps.DEFAULT_OPTS, **(opts or {})}
+    ax, ay = ps.coarse_axes(opts)
+    nx, ny = len(ax), len(ay)
+    with torch.cuda.device(dev):
+        peaks = torch.zeros(B, max_peaks, 3, dtype=torch.float64, device=dev)
+        counts = torch.zeros(B, dtype=torch.int32, device=dev)
+        if nx == 0 or ny == 0:
+            return peaks, counts
+        tx = torch.from_numpy(ax).to(dev)
+        ty = torch.from_numpy(ay).to(dev)
+        need = lib.admmnet_peak_search_workspace_bytes(xbase, ybase, nx, ny, B)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        o7 = (_ct.c_double * 7)(so["xmin"], so["xmax"], so["xstep"], so["ymin"], so["ymax"], so["ystep"],
+                               so["reducefactor"])
+        phi = phi.to(torch.complex64).contiguous()
+        _lib.check(lib.admmnet_peak_search_f64(_ptr(phi), B, xbase, ybase, _ptr(tx), nx, _ptr(ty), ny, o7,
+                                               int(so["iter"]), max_peaks, _ptr(peaks), _ptr(counts), _ptr(ws), need,
+                                               _stream(dev)), "admmnet_peak_search_f64")
+    return peaks, counts

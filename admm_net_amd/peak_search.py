@@ -133,17 +133,28 @@ def coarse_axes(opts=None):
             np.arange(so["ymin"], so["ymax"] - so["xstep"], so["ystep"]))
 
 
-def batched_peak_search(phi, xbase, ybase, opts=None, top=None):
+def batched_peak_search(phi, xbase, ybase, opts=None, top=None, max_peaks=256, host_refine=False):
     """Peak search for a batch phi [B, D] (torch tensor on the HIP device).
 
-    The coarse-grid spectra of all signals are evaluated in one launch of the HIP
-    spectrum kernel; regional maxima and the local refinement rounds run on the host
-    exactly as ``alt_peak_search``.  Returns a list of [num_peaks, 3] arrays, each
-    sorted by height (descending) and truncated to ``top`` rows when given, as the
-    callers do (main_for_net.py:119,126).
+    Everything runs on the device (``ops.peak_search``: spectrum, regional maxima, refinement rounds, one
+    signal per workgroup); only the [B, max_peaks, 3] result comes back.  ``host_refine=True`` keeps the
+    earlier split (device spectrum, host maxima + refinement = ``alt_peak_search`` verbatim) for A/B checks.
+    Returns a list of [num_peaks, 3] arrays, each sorted by height (descending, stable) and truncated to
+    ``top`` rows when given, as the callers do (main_for_net.py:119,126).
     """
     import torch
     from . import ops
+    if not host_refine:
+        pk, cnt = ops.peak_search(phi, xbase, ybase, opts, max_peaks)
+        pk, cnt = pk.cpu().numpy(), cnt.cpu().numpy()
+        if int(cnt.max(initial=0)) > max_peaks:
+            raise ValueError(f"{int(cnt.max())} regional maxima exceed max_peaks={max_peaks}")
+        out = []
+        for i in range(pk.shape[0]):
+            r = pk[i, :cnt[i]]
+            r = r[np.argsort(-r[:, 2], kind="stable")]
+            out.append(r[:top] if top else r)
+        return out
     ax, ay = coarse_axes(opts)
     Z = ops.spectrum(phi, xbase, ybase, torch.from_numpy(ax), torch.from_numpy(ay)).cpu().numpy()
     phis = phi.detach().cpu().numpy()

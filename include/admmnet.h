@@ -162,6 +162,22 @@ int admmnet_spectrum_f64(const void *phi, int64_t B, int32_t xbase, int32_t ybas
                          const double *taus, int32_t nx, const double *fs, int32_t ny,
                          double *out, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* Batched grid peak search on that spectrum: alt_peak_search, utils/peakSearchUtils.py:63-173
+ * (coarse grid -> regional maxima, skimage local_maxima(connectivity=2) semantics -> `iters`
+ * refinement rounds), one signal per workgroup.
+ *   axis_x [nx], axis_y [ny]: the coarse grid (np.arange(xmin, xmax - xstep, xstep) and the
+ *     reference's np.arange(ymin, ymax - xstep, ystep), :105-106), device float64;
+ *   opts7 (host): xmin, xmax, xstep, ymin, ymax, ystep, reducefactor;
+ *   peaks device float64 [B][max_peaks][3] = (x = tau, y = f, height) in np.where row-major order
+ *     of the coarse maxima (callers sort by height, main_for_net.py:119); rows >= count are not written;
+ *   counts device int32 [B]: number of regional maxima found (may exceed max_peaks: truncated);
+ *   workspace: device scratch of admmnet_peak_search_workspace_bytes() bytes (tables + coarse spectra). */
+int64_t admmnet_peak_search_workspace_bytes(int32_t xbase, int32_t ybase, int32_t nx, int32_t ny, int64_t B);
+int admmnet_peak_search_f64(const void *phi, int64_t B, int32_t xbase, int32_t ybase,
+                            const double *axis_x, int32_t nx, const double *axis_y, int32_t ny,
+                            const double *opts7, int32_t iters, int32_t max_peaks, double *peaks,
+                            int32_t *counts, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- measurement hooks (bench.py roofline leg) ---------------------------------
  * When enabled, every kernel launcher brackets its launch with HIP events on the
  * caller's stream.  admmnet_profile_read synchronises those events, returns the

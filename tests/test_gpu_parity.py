@@ -294,3 +294,27 @@ def test_spectrum_and_peak_indices(dev):
         host = host[np.argsort(-host[:, 2], kind="stable")][:3]
         assert np.array_equal(got[i][:, :2], host[:, :2])
         assert np.abs(got[i][:, 2] - host[:, 2]).max() < 1e-9 * host[:, 2].max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(10, 10, 1), (8, 16, 2), (16, 16, 1)], ids=["10x10", "8x16", "16x16"])
+def test_device_peak_search_matches_host(dev, geom):
+    """ops.peak_search (spectrum + regional maxima + refinement on the device, peaks.hip) against the host
+    mirror of alt_peak_search on the same phi: same maxima in the same (np.where) order, coordinates bit-exact,
+    heights to float64 rounding."""
+    Nb, Nd, iters = geom
+    y, b, s, _ = synth.make_batch(6, Nb, Nd, seed=23, snr_range=(10.0, 20.0))
+    torch.manual_seed(2)
+    m = A.PhiEstADMMNet(M=Nb, N=Nd, num_layers=3).eval()
+    phi = m(torch.from_numpy(y).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(s).to(dev))
+    opts = {"xstep": 1 / (4 * Nd), "ystep": 1 / (4 * Nb), "iter": iters}
+    pk, cnt = ops.peak_search(phi, Nb, Nd, opts, max_peaks=512)
+    pk, cnt = pk.cpu().numpy(), cnt.cpu().numpy()
+    ph = phi.cpu().numpy()
+    for i in range(ph.shape[0]):
+        host = peak_search.alt_peak_search({"phi": ph[i], "xbase": Nb, "ybase": Nd}, opts)
+        assert cnt[i] == host.shape[0] and cnt[i] > 0
+        got = pk[i, :cnt[i]]
+        assert np.array_equal(got[:, :2], host[:, :2])
+        assert np.abs(got[:, 2] - host[:, 2]).max() <= 1e-9 * host[:, 2].max()
+        assert not pk[i, cnt[i]:].any()

@@ -1,0 +1,54 @@
+"""The alternative kernel paths stay correct: each A/B switch of INTEGRATION.md section 6 is read once per
+process, so every variant runs in a child process on the golden fixtures of the reference and must meet the
+same tolerance as the default path."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import glob, json, os, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+import admm_net_amd as A
+dev = torch.device("cuda:0")
+out = {{}}
+for name in ("phiest_8x16_K3_perturbed", "admmnet_10x10_K3_default", "phiest_16x16_K3_perturbed"):
+    z = np.load(os.path.join({root!r}, "tests", "golden", name + ".npz"))
+    Nb, Nd, K, B, L, head, s2d = [int(v) for v in z["meta"]]
+    sd = {{k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}}
+    m = (A.ADMMNet if head else A.PhiEstADMMNet)(M=Nb, N=Nd, L=L, num_layers=K)
+    m.load_state_dict(sd)
+    m.eval()
+    y, b, s = (torch.from_numpy(z[k]).to(dev) for k in ("y", "b", "sigma"))
+    r = m(y, b, s)
+    phi = (r[3] if head else r).cpu().numpy()
+    ref = z["phi"]
+    out[name] = float(np.abs(phi - ref).max() / np.abs(ref).max())
+print("RESULT " + json.dumps(out))
+"""
+
+VARIANTS = {
+    "eig_ql": {"ADMMNET_EIG": "ql"},
+    "no_arrow": {"ADMMNET_ARROW": "0"},
+    "unfused_back": {"ADMMNET_FUSE_BACK": "0", "ADMMNET_ARROW": "0"},
+    "tridiag_lds": {"ADMMNET_TRIDIAG": "lds", "ADMMNET_ARROW": "0"},
+}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_variant_matches_reference_fixtures(variant):
+    env = dict(os.environ, **VARIANTS[variant])
+    p = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT)], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    errs = json.loads(line[len("RESULT "):])
+    assert len(errs) == 3
+    for name, e in errs.items():
+        assert e < 1e-4, (variant, name, e)
