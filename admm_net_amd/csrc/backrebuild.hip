@@ -135,6 +135,7 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     for (int s = 0; s < (NSLAB > 0 ? NSLAB : nslab); ++s) {
         const int buf = s & 1;
         if (s + 1 < nslab) gload((s + 1) * BR_KS);
+        mark(6);
         if (wact) {
             const float *sa = slabA + (size_t)buf * BR_KS * BR_AP, *sb = slabB + (size_t)buf * BR_KS * BP;
             // operands of k-step kk + 1 are read from LDS before the MFMAs of k-step kk are issued
@@ -167,8 +168,11 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
                 bI_cur = bI_nxt;
             }
         }
+        mark(7);
         if (s + 1 < nslab) lstore(buf ^ 1);
+        mark(8);
         __syncthreads();
+        mark(9);
     }
 
     mark(2);
@@ -224,9 +228,10 @@ int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, c
         ADMM_HIP(hipMemcpyAsync(hb, ptime, sizeof(hb), hipMemcpyDeviceToHost, st));
         ADMM_HIP(hipStreamSynchronize(st));
         ADMM_HIP(hipFree(ptime));
-        static const char *nm[6] = {"eig map", "first slab", "phase A", "phase B", "phase C", "arrow+norm"};
+        static const char *nm[10] = {"eig map", "first slab", "phase A rest", "phase B", "phase C", "arrow+norm",
+                                     "A: gload", "A: mfma", "A: lstore", "A: barrier"};
         fprintf(stderr, "[back_rebuild timing] D=%d nb=%lld  mean cycles per workgroup:\n", D, (long long)nb);
-        for (int i = 0; i < 6; ++i) fprintf(stderr, "   %-12s %10.0f\n", nm[i], (double)hb[i] / (double)nb);
+        for (int i = 0; i < 10; ++i) fprintf(stderr, "   %-12s %10.0f\n", nm[i], (double)hb[i] / (double)nb);
     }
     const int n = D + 1;
     if (w_out) ADMM_HIP(hipMemcpyAsync(w_out, ws.w, sizeof(float) * nb * n, hipMemcpyDeviceToDevice, st));
