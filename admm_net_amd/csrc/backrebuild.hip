@@ -42,7 +42,7 @@ __host__ __device__ inline size_t br_lds_bytes(const BrGeom &g) {
 // wait in front of every MFMA pair)
 // NSLAB > 0: compile-time slab count (the slab loop is fully unrolled: with a loop back-edge the 160
 // accumulators are carried in VGPRs and copied to and from the AGPRs around every slab); 0: run-time count.
-template <int NCT, int NSLAB>
+template <int NCT, int NSLAB, bool VEC>
 __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     int D, const float *__restrict__ lw, const float *__restrict__ Wbuf, const float *__restrict__ QT,
     const float *__restrict__ wv, const float *__restrict__ w0v, const float2 *__restrict__ phi,
@@ -94,30 +94,80 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     }
 
     // ---------------- phase A: VT = W^T-rows x QT on the matrix cores, K streamed through LDS ------
-    // staging registers of one slab: thread t carries column t of every slab row (A: t < 160 columns c,
-    // B: t < BP columns rho'), so global loads and LDS stores are contiguous across the workgroup
-    float ra[BR_KS], rb[BR_KS];
+    // Slab staging.  The 16 rows (1 + r0 ...) of W that make the A slab are ONE contiguous span of 16 n floats
+    // (row pitch = row length), copied by all 256 threads with a dword per lane (W rows are only 4-byte
+    // aligned; misaligned 16-byte loads measured 2x slower than dwords) and scattered to the padded LDS rows.
+    // D % 4 == 0 (every geometry of the reference): the 16 x 2D B slab (QT rows, 16-byte aligned) moves as
+    // float4 chunks, 4 per thread at D = 128.  Otherwise thread t carries column t of every B row.
+    constexpr bool vec = VEC;   // D % 4 == 0
+    constexpr int NAS = (BR_KS * 129 + BR_THREADS - 1) / BR_THREADS;   // 9: span elements per thread (n <= 129)
+    constexpr int NBV = BR_KS * (2 * 128 / 4) / BR_THREADS;            // 4 at D = 128
+    float sa_reg[NAS];
+    float4 vb[NBV];
+    float rb[BR_KS];
     const bool bim = tid >= Dp;
     const int bo = bim ? tid - Dp : tid;                   // offset inside the real / imaginary plane
-    const bool bval = tid < BP && bo < D, aval = tid < n;
+    const bool bval = tid < BP && bo < D;
     const float *qcol = Q + (bim ? D : 0) + (bval ? bo : 0);
-    const float *wcol = Wr + n + (aval ? tid : 0);         // row 1 + r of W
+    const int cpr = D / 2;                                 // B chunks per row (2 D / 4)
+    const int a_row0 = tid / n, a_col0 = tid - a_row0 * n;
+    const int a_drow = BR_THREADS / n, a_dcol = BR_THREADS - a_drow * n;
     auto gload = [&](int r0) {
+        const int rows = min(BR_KS, D - r0);               // valid rows of this slab
+        const float *span = Wr + (int64_t)(1 + r0) * n;
 #pragma unroll
-        for (int q = 0; q < BR_KS; ++q) {
-            const int r = r0 + q;
-            ra[q] = (aval && r < D) ? wcol[(int64_t)r * n] : 0.f;
-            rb[q] = (bval && r < D) ? qcol[(int64_t)r * 2 * D] : 0.f;
+        for (int q = 0; q < NAS; ++q) {
+            const int e = tid + q * BR_THREADS;
+            sa_reg[q] = (e < rows * n) ? span[e] : 0.f;
+        }
+        if constexpr (vec) {
+#pragma unroll
+            for (int q = 0; q < NBV; ++q) {
+                const int idx = tid + q * BR_THREADS;
+                const int row = idx / cpr, gq = idx - row * cpr;
+                const int r = r0 + row;
+                vb[q] = (row < BR_KS && r < D) ? *reinterpret_cast<const float4 *>(Q + (int64_t)r * 2 * D + 4 * gq)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < BR_KS; ++q) rb[q] = (bval && r0 + q < D) ? qcol[(int64_t)(r0 + q) * 2 * D] : 0.f;
         }
     };
     auto lstore = [&](int buf) {
         float *sa = slabA + (size_t)buf * BR_KS * BR_AP, *sb = slabB + (size_t)buf * BR_KS * BP;
+        int row = a_row0, c = a_col0;   // (row, column) of span element tid, then + 256 elements per step
 #pragma unroll
-        for (int q = 0; q < BR_KS; ++q) {
-            if (tid < BR_AP) sa[q * BR_AP + tid] = ra[q];
-            if (tid < BP) sb[q * BP + tid] = rb[q];
+        for (int q = 0; q < NAS; ++q) {
+            if (row < BR_KS) sa[row * BR_AP + c] = sa_reg[q];   // columns [n, 160) stay zero (cleared once below)
+            row += a_drow;
+            c += a_dcol;
+            if (c >= n) {
+                c -= n;
+                ++row;
+            }
+        }
+        if constexpr (vec) {
+#pragma unroll
+            for (int q = 0; q < NBV; ++q) {
+                const int idx = tid + q * BR_THREADS;
+                const int row = idx / cpr, gq = idx - row * cpr;
+                if (row < BR_KS) {
+                    const int o = 4 * gq;                       // float offset inside the 2 D global row
+                    const int lo = (o >= D) ? Dp + (o - D) : o;   // real plane | imaginary plane (padded to Dp)
+                    *reinterpret_cast<float4 *>(sb + row * BP + lo) = vb[q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < BR_KS; ++q)
+                if (tid < BP) sb[q * BP + tid] = rb[q];
         }
     };
+    // the padding columns of both A slab buffers (c in [n, 160)) and, when D % 32 != 0, of the B planes are
+    // never written by the staging: clear the slab area once
+    for (int i = tid; i < (int)br_slab_floats(g); i += BR_THREADS) big[i] = 0.f;
+    __syncthreads();
     f32x16 accR[NCT], accI[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
@@ -135,7 +185,6 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     for (int s = 0; s < (NSLAB > 0 ? NSLAB : nslab); ++s) {
         const int buf = s & 1;
         if (s + 1 < nslab) gload((s + 1) * BR_KS);
-        mark(6);
         if (wact) {
             const float *sa = slabA + (size_t)buf * BR_KS * BR_AP, *sb = slabB + (size_t)buf * BR_KS * BP;
             // operands of k-step kk + 1 are read from LDS before the MFMAs of k-step kk are issued
@@ -168,11 +217,8 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
                 bI_cur = bI_nxt;
             }
         }
-        mark(7);
         if (s + 1 < nslab) lstore(buf ^ 1);
-        mark(8);
         __syncthreads();
-        mark(9);
     }
 
     mark(2);
@@ -209,9 +255,13 @@ int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, c
     const BrGeom g(D);
     const size_t lds = br_lds_bytes(g);
     const int nct = (D + 1 + 31) / 32;
-    auto kern = nct == 1 ? back_rebuild_kernel<1, 0> : nct == 2 ? back_rebuild_kernel<2, 0>
-              : nct == 3 ? back_rebuild_kernel<3, 0> : nct == 4 ? back_rebuild_kernel<4, 0>
-              : D == 128 ? back_rebuild_kernel<5, 8> : back_rebuild_kernel<5, 0>;
+    const bool v4 = (D & 3) == 0;   // 16-byte slab staging
+    auto kern = nct == 1   ? (v4 ? back_rebuild_kernel<1, 0, true> : back_rebuild_kernel<1, 0, false>)
+                : nct == 2 ? (v4 ? back_rebuild_kernel<2, 0, true> : back_rebuild_kernel<2, 0, false>)
+                : nct == 3 ? (v4 ? back_rebuild_kernel<3, 0, true> : back_rebuild_kernel<3, 0, false>)
+                : nct == 4 ? (v4 ? back_rebuild_kernel<4, 0, true> : back_rebuild_kernel<4, 0, false>)
+                : D == 128 ? back_rebuild_kernel<5, 8, true>
+                           : (v4 ? back_rebuild_kernel<5, 0, true> : back_rebuild_kernel<5, 0, false>);
     ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
     static const bool timing = getenv("ADMMNET_BR_TIMING") != nullptr;   // developer aid, never on by default
@@ -228,10 +278,9 @@ int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, c
         ADMM_HIP(hipMemcpyAsync(hb, ptime, sizeof(hb), hipMemcpyDeviceToHost, st));
         ADMM_HIP(hipStreamSynchronize(st));
         ADMM_HIP(hipFree(ptime));
-        static const char *nm[10] = {"eig map", "first slab", "phase A rest", "phase B", "phase C", "arrow+norm",
-                                     "A: gload", "A: mfma", "A: lstore", "A: barrier"};
+        static const char *nm[6] = {"eig map", "first slab", "phase A", "phase B", "phase C", "arrow+norm"};
         fprintf(stderr, "[back_rebuild timing] D=%d nb=%lld  mean cycles per workgroup:\n", D, (long long)nb);
-        for (int i = 0; i < 10; ++i) fprintf(stderr, "   %-12s %10.0f\n", nm[i], (double)hb[i] / (double)nb);
+        for (int i = 0; i < 6; ++i) fprintf(stderr, "   %-12s %10.0f\n", nm[i], (double)hb[i] / (double)nb);
     }
     const int n = D + 1;
     if (w_out) ADMM_HIP(hipMemcpyAsync(w_out, ws.w, sizeof(float) * nb * n, hipMemcpyDeviceToDevice, st));
