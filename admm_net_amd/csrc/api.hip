@@ -169,7 +169,7 @@ static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream
     int rc;
     if ((rc = launch_tridiag(D, nb, ws, st))) return rc;
     if (ws.Wdc) {   // divide & conquer + V = Q W on the matrix cores
-        if ((rc = launch_dc(D + 1, nb, ws, status, st))) return rc;
+        if ((rc = launch_dc(D + 1, nb, ws, status, st, with_v))) return rc;   // fused consumer reads WT itself
         return with_v ? launch_vgemm(D, nb, ws, st) : ADMMNET_OK;
     }
     if ((rc = launch_tql(D + 1, nb, ws, status, st))) return rc;

@@ -29,7 +29,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int BR_THREADS = 256;
 constexpr int BR_KS = 16;          // K rows per slab
 constexpr int BR_NCT = 5;          // eigenvector tiles: n <= 129 + padding
-constexpr int BR_AP = 32 * BR_NCT; // slab A row pitch (floats)
+constexpr int BR_AP = 32 * BR_NCT + 1; // slab A row pitch (floats): odd, the transposing LDS stores of the staging spread over the banks
 
 // slab double buffer of phase A
 __host__ __device__ inline size_t br_slab_floats(const BrGeom &g) { return (size_t)2 * BR_KS * (BR_AP + g.BP); }
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     int D, const float *__restrict__ lw, const float *__restrict__ Wbuf, const float *__restrict__ QT,
     const float *__restrict__ wv, const float *__restrict__ w0v, const float2 *__restrict__ phi,
     const float *__restrict__ h, float2 *__restrict__ G, float *__restrict__ rn,
-    unsigned long long *__restrict__ ptime) {
+    unsigned long long *__restrict__ ptime, int64_t wt_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // developer phase timer (ADMMNET_BR_TIMING=1): cycles of thread 0 between marks
     long long t_prev = ptime ? clock64() : 0;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     float *slabB = big + (size_t)2 * BR_KS * BR_AP;  // [2][KS][BP]
     float *VTl = big;                                // [n][VP] (phase B onwards)
 
-    const float *Wr = Wbuf + b * (int64_t)3 * n * n + (int64_t)2 * n * n;   // W[i][j] row-major (dc.hip)
+    const float *WT = Wbuf + b * (int64_t)3 * n * n + wt_off;   // WT[c][i] = W[i][c], c = eigenvalue (dc.hip)
     const float *Q = QT + b * ((int64_t)n * 2 * D);                         // QT[r][rho], pitch 2D
 
     {   // eigenvalue map (independent of phase A: overlaps its first loads)
@@ -94,13 +94,14 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     }
 
     // ---------------- phase A: VT = W^T-rows x QT on the matrix cores, K streamed through LDS ------
-    // Slab staging.  The 16 rows (1 + r0 ...) of W that make the A slab are ONE contiguous span of 16 n floats
-    // (row pitch = row length), copied by all 256 threads with a dword per lane (W rows are only 4-byte
-    // aligned; misaligned 16-byte loads measured 2x slower than dwords) and scattered to the padded LDS rows.
+    // Slab staging.  A[c][k = r] = W[1 + r][c] = WT[c][1 + r]: the D&C kernel leaves the eigenvectors
+    // transposed (WT[c][.] contiguous), so a 16-row slab is 16 consecutive floats of every WT row c: element
+    // e = 16 c + rl is loaded by thread e (mod 256) -- 64-byte runs, 4 rows per wave-load -- and stored
+    // transposed into the slab (row pitch 161: odd, the 16 lanes of a run hit 16 different banks).
     // D % 4 == 0 (every geometry of the reference): the 16 x 2D B slab (QT rows, 16-byte aligned) moves as
     // float4 chunks, 4 per thread at D = 128.  Otherwise thread t carries column t of every B row.
     constexpr bool vec = VEC;   // D % 4 == 0
-    constexpr int NAS = (BR_KS * 129 + BR_THREADS - 1) / BR_THREADS;   // 9: span elements per thread (n <= 129)
+    constexpr int NAS = (BR_KS * 129 + BR_THREADS - 1) / BR_THREADS;   // 9: slab elements per thread (n <= 129)
     constexpr int NBV = BR_KS * (2 * 128 / 4) / BR_THREADS;            // 4 at D = 128
     float sa_reg[NAS];
     float4 vb[NBV];
@@ -110,15 +111,14 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     const bool bval = tid < BP && bo < D;
     const float *qcol = Q + (bim ? D : 0) + (bval ? bo : 0);
     const int cpr = D / 2;                                 // B chunks per row (2 D / 4)
-    const int a_row0 = tid / n, a_col0 = tid - a_row0 * n;
-    const int a_drow = BR_THREADS / n, a_dcol = BR_THREADS - a_drow * n;
+    const int a_rl = tid & (BR_KS - 1), a_c0 = tid / BR_KS;   // thread -> (row of the slab, first eigenvector c)
     auto gload = [&](int r0) {
-        const int rows = min(BR_KS, D - r0);               // valid rows of this slab
-        const float *span = Wr + (int64_t)(1 + r0) * n;
+        const bool rok = r0 + a_rl < D;
+        const float *src = WT + 1 + r0 + a_rl;
 #pragma unroll
         for (int q = 0; q < NAS; ++q) {
-            const int e = tid + q * BR_THREADS;
-            sa_reg[q] = (e < rows * n) ? span[e] : 0.f;
+            const int c = a_c0 + q * (BR_THREADS / BR_KS);
+            sa_reg[q] = (rok && c < n) ? src[(int64_t)c * n] : 0.f;
         }
         if constexpr (vec) {
 #pragma unroll
@@ -136,16 +136,10 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     };
     auto lstore = [&](int buf) {
         float *sa = slabA + (size_t)buf * BR_KS * BR_AP, *sb = slabB + (size_t)buf * BR_KS * BP;
-        int row = a_row0, c = a_col0;   // (row, column) of span element tid, then + 256 elements per step
 #pragma unroll
         for (int q = 0; q < NAS; ++q) {
-            if (row < BR_KS) sa[row * BR_AP + c] = sa_reg[q];   // columns [n, 160) stay zero (cleared once below)
-            row += a_drow;
-            c += a_dcol;
-            if (c >= n) {
-                c -= n;
-                ++row;
-            }
+            const int c = a_c0 + q * (BR_THREADS / BR_KS);
+            if (c < n) sa[a_rl * BR_AP + c] = sa_reg[q];   // columns [n, 161) stay zero (cleared once below)
         }
         if constexpr (vec) {
 #pragma unroll
@@ -271,7 +265,7 @@ int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, c
         ADMM_HIP(hipMemsetAsync(ptime, 0, 16 * sizeof(unsigned long long), st));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(BR_THREADS), lds, st, D, lw, ws.Wdc, ws.QV,
-                       ws.w, ws.w0, phi, h, G, rn, ptime);
+                       ws.w, ws.w0, phi, h, G, rn, ptime, dc_final_offset(D + 1));
     ADMM_HIP(hipGetLastError());
     if (timing) {
         unsigned long long hb[16];

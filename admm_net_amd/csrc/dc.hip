@@ -46,7 +46,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                                                         const float *__restrict__ eT, float *__restrict__ Wbuf,
                                                         float *__restrict__ wout, float *__restrict__ w0out,
                                                         int *__restrict__ logn, int32_t *__restrict__ status,
-                                                        unsigned long long *__restrict__ ptime) {
+                                                        unsigned long long *__restrict__ ptime, int rowmajor) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ DcShared sh;
     const int tid = threadIdx.x;
@@ -305,10 +305,18 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         // P6: new blocks.  Deflated columns are copied, the others come from the GEMM
         //     WTdst[rank(j)][i] = sum_kk U[kk][j] * WTsrc[col(src[kk])][i]   (MFMA, waves take tiles)
         if (act) {
-            for (int p = k + (tl / 32); p < nn; p += max(1, ts / 32)) {   // 32 lanes per column copy
+            const int cw = ts >= 32 ? 32 : ts;   // lanes per column copy
+            for (int p = k + (tl / cw); p < nn; p += max(1, ts / cw)) {
                 const float *xs = Ws + (int64_t)(a + cidx[a + p]) * n + a;
                 float *xd = Wd + (int64_t)(a + rnk[a + p]) * n + a;
-                for (int i = (ts >= 32 ? (tl & 31) : tl); i < nn; i += (ts >= 32 ? 32 : ts)) xd[i] = xs[i];
+                for (int i = tl & (cw - 1); i < nn; i += 4 * cw) {   // four loads in flight per lane
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (i + q * cw < nn) ? xs[i + q * cw] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (i + q * cw < nn) xd[i + q * cw] = v[q];
+                }
             }
         }
         if (odd) {   // pass the unpaired block through
@@ -397,13 +405,14 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         Ws = Wd;
         Wd = tmp;
     }
-    // ---- outputs: eigenvalues (ascending), first row of W, status, and W row-major (W[i][j], j =
-    //      eigenvalue) in the U region: the orientation the V = Q W product reads coalesced
+    // ---- outputs: eigenvalues (ascending), first row of W, status, and -- unless the consumer reads the
+    //      transposed image itself (backrebuild.hip; dc_final_offset() tells it which ping-pong buffer) -- W
+    //      row-major (W[i][j], j = eigenvalue) in the third region: the orientation vgemm_kernel reads coalesced
     for (int i = tid; i < n; i += DC_THREADS) {
         wout[bm * n + i] = lam[i];
         w0out[bm * n + i] = Ws[(int64_t)i * n];
     }
-    {
+    if (rowmajor) {
         float *tile = leafZ;   // 32 x 33 floats (the leaf scratch is dead by now)
         const int tt = (n + 31) >> 5;
         const int lx = tid & 31, ly = tid >> 5;   // 32 x 8 threads
@@ -477,7 +486,18 @@ size_t dc_lds_bytes(int n) {
     return sizeof(float) * 11 * NP + sizeof(int) * 5 * NP + sizeof(DcRot) * NP + sizeof(float) * leaf;
 }
 
-int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st) {
+// float offset (inside one matrix' 3 n^2 block) of the ping-pong buffer that holds the final WT[j][i]: the
+// merge loop swaps buffers once per level
+int64_t dc_final_offset(int n) {
+    int nblk = n / DC_LS > 0 ? n / DC_LS : 1, levels = 0;
+    while (nblk > 1) {
+        nblk = (nblk >> 1) + (nblk & 1);
+        ++levels;
+    }
+    return (levels & 1) ? (int64_t)n * n : 0;
+}
+
+int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool rowmajor) {
     ProfScope _prof(KC_TQL, st);
     if (nb <= 0) return ADMMNET_OK;
     if (n / DC_LS > DC_MAXLEAF) {
@@ -496,7 +516,7 @@ int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st) 
         ADMM_HIP(hipMemsetAsync(ptime, 0, 64 * sizeof(unsigned long long), st));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(DC_THREADS), lds, st, n, ws.dT, ws.eT, ws.Wdc, ws.w,
-                       ws.w0, ws.logn, status, ptime);
+                       ws.w0, ws.logn, status, ptime, rowmajor ? 1 : 0);
     ADMM_HIP(hipGetLastError());
     if (timing) {
         unsigned long long h[64];

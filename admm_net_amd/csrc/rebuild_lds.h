@@ -60,10 +60,12 @@ __device__ __forceinline__ void rebuild_from_lds(const BrGeom &g, int64_t b, con
         constexpr int U = 4;
         const int nks = (n + 1) / 2;
         float fx[U], xr[U], xi[U], yr[U], yi[U];
-        auto lds_group = [&](int ks0, float (&f_)[U], float (&xr_)[U], float (&xi_)[U], float (&yr_)[U],
-                             float (&yi_)[U]) {
+        // u in [U0, U1) of one group of 4 K-steps
+        auto lds_part = [&](int ks0, int U0, int U1, float (&f_)[U], float (&xr_)[U], float (&xi_)[U],
+                            float (&yr_)[U], float (&yi_)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                if (u < U0 || u >= U1) continue;
                 const int c = min(2 * (ks0 + u) + kh, n);
                 const float *row = VTl + min(c, n - 1) * VP + l32;
                 f_[u] = fs[c];
@@ -73,10 +75,11 @@ __device__ __forceinline__ void rebuild_from_lds(const BrGeom &g, int64_t b, con
                 yi_[u] = row[Dp + j0];
             }
         };
-        auto mfma_group = [&](const float (&f_)[U], const float (&xr_)[U], const float (&xi_)[U],
-                              const float (&yr_)[U], const float (&yi_)[U]) {
+        auto mfma_part = [&](int U0, int U1, const float (&f_)[U], const float (&xr_)[U], const float (&xi_)[U],
+                             const float (&yr_)[U], const float (&yi_)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                if (u < U0 || u >= U1) continue;
                 const float ar = xr_[u] * f_[u], ai = xi_[u] * f_[u];
                 aRe = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, yr_[u], aRe, 0, 0, 0);
                 aIm = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, yr_[u], aIm, 0, 0, 0);
@@ -84,24 +87,33 @@ __device__ __forceinline__ void rebuild_from_lds(const BrGeom &g, int64_t b, con
                 aIm = __builtin_amdgcn_mfma_f32_32x32x2f32(-ar, yi_[u], aIm, 0, 0, 0);
             }
         };
-        // two register sets in ping-pong, no copies; sched_barrier pins "next group's reads first, then this
-        // group's MFMAs" (left alone, the scheduler defers half of the reads to just before their use and
-        // drains the LDS queue at the end of every trip)
+        // Two register sets in ping-pong, no copies.  The reads of the NEXT group are issued ahead of the MFMAs
+        // of the current one, ten at a time: lgkmcnt is a 4-bit counter, so with more than 15 younger reads in
+        // flight "wait for the older ones" is not expressible and the compiler falls back to lgkmcnt(0) -- a
+        // full LDS round trip in front of every group.  sched_barrier pins the order.
         float fb[U], xrb[U], xib[U], yrb[U], yib[U];
         const int ngrp = (nks + U - 1) / U;
-        lds_group(0, fx, xr, xi, yr, yi);
+        lds_part(0, 0, U, fx, xr, xi, yr, yi);
         int gq = 0;
         for (; gq + 1 < ngrp; gq += 2) {
-            lds_group((gq + 1) * U, fb, xrb, xib, yrb, yib);
+            lds_part((gq + 1) * U, 0, 2, fb, xrb, xib, yrb, yib);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_group(fx, xr, xi, yr, yi);
+            mfma_part(0, 2, fx, xr, xi, yr, yi);
             __builtin_amdgcn_sched_barrier(0);
-            lds_group((gq + 2) * U, fx, xr, xi, yr, yi);   // (past the end: clamped, exact zeros, unused)
+            lds_part((gq + 1) * U, 2, 4, fb, xrb, xib, yrb, yib);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_group(fb, xrb, xib, yrb, yib);
+            mfma_part(2, 4, fx, xr, xi, yr, yi);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_part((gq + 2) * U, 0, 2, fx, xr, xi, yr, yi);   // (past the end: clamped, exact zeros, unused)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_part(0, 2, fb, xrb, xib, yrb, yib);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_part((gq + 2) * U, 2, 4, fx, xr, xi, yr, yi);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_part(2, 4, fb, xrb, xib, yrb, yib);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (gq < ngrp) mfma_group(fx, xr, xi, yr, yi);
+        if (gq < ngrp) mfma_part(0, U, fx, xr, xi, yr, yi);
         // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
