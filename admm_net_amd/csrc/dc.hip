@@ -210,6 +210,12 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         __syncthreads();
         mark(3);
         const int k = act ? sh.kk[team] : 0;
+        if (ptime && act && tl == 0) {   // developer statistics: merge sizes, non-deflated counts, rotations per level
+            atomicAdd(&ptime[64 + 4 * min(lvl, 5) + 0], (unsigned long long)nn);
+            atomicAdd(&ptime[64 + 4 * min(lvl, 5) + 1], (unsigned long long)k);
+            atomicAdd(&ptime[64 + 4 * min(lvl, 5) + 2], (unsigned long long)sh.nrot[team]);
+            atomicAdd(&ptime[64 + 4 * min(lvl, 5) + 3], 1ull);
+        }
         // P3: deflation rotations on the source columns (thread-private rows i) + secular roots
         if (act) {
             // A chain of rotations (pa, pb) hands column pb on as the next pa: each thread keeps its
@@ -512,14 +518,14 @@ int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, 
     static const bool timing = getenv("ADMMNET_DC_TIMING") != nullptr;   // developer aid, never on by default
     unsigned long long *ptime = nullptr;
     if (timing) {
-        ADMM_HIP(hipMalloc(&ptime, 64 * sizeof(unsigned long long)));
-        ADMM_HIP(hipMemsetAsync(ptime, 0, 64 * sizeof(unsigned long long), st));
+        ADMM_HIP(hipMalloc(&ptime, 96 * sizeof(unsigned long long)));
+        ADMM_HIP(hipMemsetAsync(ptime, 0, 96 * sizeof(unsigned long long), st));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(DC_THREADS), lds, st, n, ws.dT, ws.eT, ws.Wdc, ws.w,
                        ws.w0, ws.logn, status, ptime, rowmajor ? 1 : 0);
     ADMM_HIP(hipGetLastError());
     if (timing) {
-        unsigned long long h[64];
+        unsigned long long h[96];
         ADMM_HIP(hipMemcpyAsync(h, ptime, sizeof(h), hipMemcpyDeviceToHost, st));
         ADMM_HIP(hipStreamSynchronize(st));
         ADMM_HIP(hipFree(ptime));
@@ -527,6 +533,11 @@ int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, 
                                      "P5 U", "P6 barrier wait", "P7 commit", "final transpose", "P6 copy", "P6 gemm"};
         fprintf(stderr, "[dc timing] n=%d nb=%lld  mean cycles per workgroup:\n", n, (long long)nb);
         for (int i = 0; i < 12; ++i) fprintf(stderr, "   %-16s %10.0f\n", nm[i], (double)h[i] / (double)nb);
+        for (int l = 0; l < 6; ++l)
+            if (h[64 + 4 * l + 3])
+                fprintf(stderr, "   level %d merges: mean size %.1f, non-deflated %.1f, rotations %.1f\n", l,
+                        (double)h[64 + 4 * l] / h[64 + 4 * l + 3], (double)h[64 + 4 * l + 1] / h[64 + 4 * l + 3],
+                        (double)h[64 + 4 * l + 2] / h[64 + 4 * l + 3]);
         for (int l = 0; l < 6; ++l) {
             fprintf(stderr, "   level %d:", l);
             for (int q = 0; q < 7; ++q) fprintf(stderr, " %8.0f", (double)h[16 + 8 * l + q] / (double)nb);
