@@ -165,9 +165,20 @@ static bool use_arrow(int D) {
     return on && arrow_rebuild_supported(D);
 }
 
-static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool with_v = true) {
+// "Lean" state (D <= 128, register-resident tridiagonalisation, arrowhead first layer): G and Z are kept as
+// lower triangles and the tridiagonalisation forms A = C - Z / rho itself, so the prep kernel only streams the
+// lazy Z update (no A image is written or read).  ADMMNET_LEAN=0 keeps full storage + the image.
+static bool use_lean(int D) {
+    static const bool on = !(getenv("ADMMNET_LEAN") && atoi(getenv("ADMMNET_LEAN")) == 0);
+    static const bool lds = getenv("ADMMNET_TRIDIAG") && !strcmp(getenv("ADMMNET_TRIDIAG"), "lds");
+    return on && !lds && D <= 128 && use_arrow(D);
+}
+
+static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool with_v = true,
+                     const float2 *Zlow = nullptr, const float2 *phi = nullptr, const float *h = nullptr,
+                     const float *lw = nullptr) {
     int rc;
-    if ((rc = launch_tridiag(D, nb, ws, st))) return rc;
+    if ((rc = launch_tridiag(D, nb, ws, st, Zlow, phi, h, lw))) return rc;
     if (ws.Wdc) {   // divide & conquer + V = Q W on the matrix cores
         if ((rc = launch_dc(D + 1, nb, ws, status, st, with_v))) return rc;   // fused consumer reads WT itself
         return with_v ? launch_vgemm(D, nb, ws, st) : ADMMNET_OK;
@@ -353,19 +364,21 @@ int admmnet_layer_front(const admmnet_cfg *cfg, const float *W, int32_t k, const
     const int cur = k & 1;
     for (int64_t b0 = 0; b0 < B; b0 += ws.chunk) {
         const int64_t nb = (B - b0 < ws.chunk) ? (B - b0) : ws.chunk;
+        const bool lean = use_lean(D);
+        const float2 *phk = ws.phi[cur] + b0 * D;
+        const float *hk = ws.h[cur] + b0 * D;
+        float2 *Gk = ws.G + b0 * n * n;
         if (k == 0 && use_arrow(D)) {   // Z = 0: arrowhead, no matrix is ever formed
             if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, ws, false, st, true))) return rc;
-            if ((rc = launch_arrow_rebuild(D, nb, lw, ws.phi[cur] + b0 * D, ws.h[cur] + b0 * D, ws.G + b0 * n * n,
-                                           ws.rn + b0, nullptr, status, st)))
-                return rc;
+            if ((rc = launch_arrow_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, status, st, lean))) return rc;
             continue;
         }
-        if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, ws, false, st))) return rc;
+        if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, ws, false, st, false, lean))) return rc;
         const bool fused = fuse_back(D, ws);
-        if ((rc = eig_chunk(D, nb, ws, status, st, !fused))) return rc;
-        if ((rc = (fused ? launch_back_rebuild : launch_rebuild)(D, nb, lw, ws.phi[cur] + b0 * D, ws.h[cur] + b0 * D,
-                                                                 ws.G + b0 * n * n, ws.rn + b0, nullptr, ws, st)))
-            return rc;
+        if ((rc = eig_chunk(D, nb, ws, status, st, !fused, lean ? ws.Z + b0 * n * n : nullptr, phk, hk, lw))) return rc;
+        rc = fused ? launch_back_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, ws, st, lean)
+                   : launch_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, ws, st, lean);
+        if (rc) return rc;
     }
     return launch_rn_sum(B, ws.rn, sum_out ? sum_out : ws.sum, st);
 }
@@ -462,10 +475,11 @@ int admmnet_glayer_f32(const admmnet_cfg *cfg, const float *lw, const void *phi,
         if ((rc = launch_build_block(D, nb, sc[S_CORNER_G], sc[S_INV_RHO_G], ph, h + b0 * D, Zc, ws, st))) return rc;
         const bool fused = fuse_back(D, ws);
         if ((rc = eig_chunk(D, nb, ws, status, st, !fused))) return rc;
-        if ((rc = (fused ? launch_back_rebuild : launch_rebuild)(
-                 D, nb, lw, ph, h + b0 * D, (float2 *)G_out + b0 * n * n, rn_out ? rn_out + b0 : rn_tmp + b0,
-                 w_out ? w_out + b0 * n : nullptr, ws, st)))
-            return rc;
+        float2 *Go = (float2 *)G_out + b0 * n * n;
+        float *rno = rn_out ? rn_out + b0 : rn_tmp + b0, *wo = w_out ? w_out + b0 * n : nullptr;
+        rc = fused ? launch_back_rebuild(D, nb, lw, ph, h + b0 * D, Go, rno, wo, ws, st)
+                   : launch_rebuild(D, nb, lw, ph, h + b0 * D, Go, rno, wo, ws, st);
+        if (rc) return rc;
     }
     return ADMMNET_OK;
 }

@@ -38,7 +38,7 @@ __host__ __device__ inline size_t ar_lds_bytes(const BrGeom &g) {
 __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
     int D, const float *__restrict__ lw, const float2 *__restrict__ phi, const float *__restrict__ h,
     float2 *__restrict__ G, float *__restrict__ rn, float *__restrict__ w_out, int32_t *__restrict__ status,
-    unsigned long long *__restrict__ ptime) {
+    unsigned long long *__restrict__ ptime, int lower_only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ ArShared sh;
     // developer phase timer (ADMMNET_AR_TIMING=1): cycles of thread 0 between marks
@@ -291,13 +291,13 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
     __syncthreads();
     mark(3);
     (void)status;
-    rebuild_from_lds(g, b, lw, VTl, fs, w0f, z0s, rowb, redb, phi, h, G, rn, [&](int id) { mark(id); });
+    rebuild_from_lds(g, b, lw, VTl, fs, w0f, z0s, rowb, redb, phi, h, G, rn, [&](int id) { mark(id); }, lower_only);
 }
 
 bool arrow_rebuild_supported(int D) { return D >= 1 && D <= 128; }
 
 int launch_arrow_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G, float *rn,
-                         float *w_out, int32_t *status, hipStream_t st) {
+                         float *w_out, int32_t *status, hipStream_t st, bool lower_only) {
     ProfScope _prof(KC_REBUILD, st);
     if (nb <= 0) return ADMMNET_OK;
     if (!arrow_rebuild_supported(D)) {
@@ -315,7 +315,7 @@ int launch_arrow_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, 
         ADMM_HIP(hipMemsetAsync(ptime, 0, 16 * sizeof(unsigned long long), st));
     }
     hipLaunchKernelGGL(arrow_rebuild_kernel, dim3((unsigned)nb), dim3(AR_THREADS), lds, st, D, lw, phi, h, G, rn,
-                       w_out, status, ptime);
+                       w_out, status, ptime, lower_only ? 1 : 0);
     ADMM_HIP(hipGetLastError());
     if (timing) {
         unsigned long long hb[16];

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     int D, const float *__restrict__ lw, const float *__restrict__ Wbuf, const float *__restrict__ QT,
     const float *__restrict__ wv, const float *__restrict__ w0v, const float2 *__restrict__ phi,
     const float *__restrict__ h, float2 *__restrict__ G, float *__restrict__ rn,
-    unsigned long long *__restrict__ ptime, int64_t wt_off) {
+    unsigned long long *__restrict__ ptime, int64_t wt_off, int lower_only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // developer phase timer (ADMMNET_BR_TIMING=1): cycles of thread 0 between marks
     long long t_prev = ptime ? clock64() : 0;
@@ -233,13 +233,13 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     __syncthreads();
     mark(3);
 
-    rebuild_from_lds(g, b, lw, VTl, fs, w0f, z0s, rowb, redb, phi, h, G, rn, mark);
+    rebuild_from_lds(g, b, lw, VTl, fs, w0f, z0s, rowb, redb, phi, h, G, rn, mark, lower_only);
 }
 
 bool back_rebuild_supported(int D) { return D >= 1 && D <= 128; }
 
 int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G,
-                        float *rn, float *w_out, const Ws &ws, hipStream_t st) {
+                        float *rn, float *w_out, const Ws &ws, hipStream_t st, bool lower_only) {
     ProfScope _prof(KC_REBUILD, st);
     if (nb <= 0) return ADMMNET_OK;
     if (!back_rebuild_supported(D) || !ws.Wdc) {
@@ -265,7 +265,7 @@ int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, c
         ADMM_HIP(hipMemsetAsync(ptime, 0, 16 * sizeof(unsigned long long), st));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(BR_THREADS), lds, st, D, lw, ws.Wdc, ws.QV,
-                       ws.w, ws.w0, phi, h, G, rn, ptime, dc_final_offset(D + 1));
+                       ws.w, ws.w0, phi, h, G, rn, ptime, dc_final_offset(D + 1), lower_only ? 1 : 0);
     ADMM_HIP(hipGetLastError());
     if (timing) {
         unsigned long long hb[16];

@@ -111,13 +111,16 @@ int64_t pick_chunk(const admmnet_cfg *cfg, int64_t B);
 // prep.hip
 int launch_prep(const admmnet_cfg *cfg, const float *lw, int k, const float2 *y, const float2 *b,
                 const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st,
-                bool no_matrix = false);
+                bool no_matrix = false, bool lean = false);
 int launch_build_generic(int n, int64_t nb, const float2 *A, const Ws &ws, hipStream_t st);
 int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const float2 *phi, const float *h,
                        const float2 *Z, const Ws &ws, hipStream_t st);
 // tridiag.hip
-int launch_tridiag(int D, int64_t nb, const Ws &ws, hipStream_t st);
-int launch_tridiag_reg(int D, int64_t nb, const Ws &ws, hipStream_t st);   // tridiag_reg.hip, D <= 128
+int launch_tridiag(int D, int64_t nb, const Ws &ws, hipStream_t st, const float2 *Zlow = nullptr,
+                   const float2 *phi = nullptr, const float *h = nullptr, const float *lw = nullptr);
+int launch_tridiag_reg(int D, int64_t nb, const Ws &ws, hipStream_t st, const float2 *Zlow = nullptr,
+                       const float2 *phi = nullptr, const float *h = nullptr,
+                       const float *lw = nullptr);   // tridiag_reg.hip, D <= 128
 int launch_tridiag_big(int D, int64_t nb, const Ws &ws, hipStream_t st);   // tridiag_big.hip, 128 < D <= 256
 // tql.hip
 int launch_tql(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st);
@@ -132,13 +135,14 @@ int launch_peaks(const float2 *phi, int64_t B, int xbase, int ybase, const doubl
                  double *peaks, int32_t *counts, hipStream_t st);                          // peaks.hip
 bool arrow_rebuild_supported(int D);                                                       // arrow.hip
 int launch_arrow_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G, float *rn,
-                         float *w_out, int32_t *status, hipStream_t st);                  // arrow.hip
+                         float *w_out, int32_t *status, hipStream_t st, bool lower_only = false);   // arrow.hip
 bool back_rebuild_supported(int D);                                                        // backrebuild.hip
 int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G,
-                        float *rn, float *w_out, const Ws &ws, hipStream_t st);           // backrebuild.hip
+                        float *rn, float *w_out, const Ws &ws, hipStream_t st,
+                        bool lower_only = false);                                        // backrebuild.hip
 bool use_dc();                                                                          // api.hip
 int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h,
-                   float2 *G, float *rn, float *w_out, const Ws &ws, hipStream_t st);
+                   float2 *G, float *rn, float *w_out, const Ws &ws, hipStream_t st, bool lower_only = false);
 int launch_vout(int n, int64_t nb, float2 *V, float *w, const Ws &ws, hipStream_t st);
 // zstep.hip
 int launch_rn_sum(int64_t B, const float *rn, double *sum, hipStream_t st);

@@ -46,6 +46,8 @@ constexpr int PM_FIRST = 1;      // layer 0: G = Z = 0, nothing is read
 constexpr int PM_ZZERO = 2;      // layer 1: stored Z is still zero (never written)
 constexpr int PM_PHI_ONLY = 4;   // last layer: only phi is needed (admm_net.py:757-764)
 constexpr int PM_NO_MATRIX = 8;  // layer 0 on the arrowhead path (arrow.hip): phi and h only, A is never formed
+constexpr int PM_LEAN = 16;      // G / Z kept as lower triangles, A built by the tridiagonalisation's own loader
+                                 // (tridiag_reg.hip): only the lazy Z update streams here, 24 n^2 / 2 bytes per signal
 
 __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
     int D, int mode, const float *__restrict__ lw, const float *__restrict__ lw_prev,
@@ -139,6 +141,28 @@ __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
     __syncthreads();
 
     if (mode & PM_NO_MATRIX) return;
+    if (mode & PM_LEAN) {
+        // Z <- Z + alpha (G - C_prev) on the lower triangle (row D = arrow row).  Two rows per trip, one per
+        // half of the workgroup: row r (r + 1 entries) and row n - 1 - r, so both halves stay busy.
+        if (first) return;
+        const float corner_zp = lw_prev[S_CORNER_Z];
+        const int half = tid >> 7, t7 = tid & 127;
+        for (int r = 0; 2 * r < n; ++r) {
+            const int i = half ? (n - 1 - r) : r;
+            if (half && i == r) break;   // middle row of an odd n: the first half takes it
+            for (int j = t7; j <= i; j += PR_THREADS / 2) {
+                const int64_t idx = (int64_t)i * n + j;
+                const float2 gij = Gs[idx];
+                const float2 zij = zzero ? make_float2(0.f, 0.f) : Zs[idx];
+                float2 c;
+                if (i < D) c = make_float2(i == j ? hp[i] : 0.f, 0.f);
+                else if (j == D) c = make_float2(corner_zp, 0.f);
+                else c = make_float2(phip[j].x, -phip[j].y);   // C[D][j] = conj(phi_prev_j)
+                Zs[idx] = make_float2(zij.x + al * (gij.x - c.x), zij.y + al * (gij.y - c.y));
+            }
+        }
+        return;
+    }
     // ---- stream the matrix: finish the lazy Z update, build A (arrow-first order)
     const float corner_g = lw[S_CORNER_G], inv_rho_g = lw[S_INV_RHO_G];
     const float corner_zp = first ? 0.f : lw_prev[S_CORNER_Z];
@@ -225,7 +249,7 @@ int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const flo
 
 int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2 *y, const float2 *b,
                 const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st,
-                bool no_matrix) {
+                bool no_matrix, bool lean) {
     ProfScope _prof(KC_PREP, st);
     if (nb <= 0) return ADMMNET_OK;
     const int D = cfg->M * cfg->N, n = D + 1;
@@ -237,6 +261,7 @@ int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2
     if (k == 1) mode |= PM_ZZERO;
     if (phi_only) mode |= PM_PHI_ONLY;
     if (no_matrix && k == 0) mode |= PM_NO_MATRIX;
+    if (lean) mode |= PM_LEAN;
     const int cur = k & 1, prv = cur ^ 1;
     const size_t lds = sizeof(float2) * 2 * D + sizeof(float) * (3 * D + kHid + 8);
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)nb), dim3(PR_THREADS), lds, st, D, mode, lw, lwp,

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(RB_THREADS) void rebuild_kernel(int D, const float 
                                                              const float *__restrict__ w0v,
                                                              const float2 *__restrict__ phi,
                                                              const float *__restrict__ h,
-                                                             float2 *__restrict__ G, float *__restrict__ rn) {
+                                                             float2 *__restrict__ G, float *__restrict__ rn,
+                                                             int lower_only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = D + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(RB_THREADS) void rebuild_kernel(int D, const float 
                     acc2 += d * d;
                 } else {
                     Gb[(int64_t)gi * n + gj] = make_float2(re, im);
-                    Gb[(int64_t)gj * n + gi] = make_float2(re, -im);
+                    if (!lower_only) Gb[(int64_t)gj * n + gi] = make_float2(re, -im);
                     acc2 += 2.f * (re * re + im * im);
                 }
             }
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(RB_THREADS) void rebuild_kernel(int D, const float 
     for (int o = tid; o < D; o += RB_THREADS) {
         const float gr = rowb[o], gim = -rowb[D + o];     // G[D][o]
         Gb[(int64_t)D * n + o] = make_float2(gr, gim);
-        Gb[(int64_t)o * n + D] = make_float2(gr, -gim);
+        if (!lower_only) Gb[(int64_t)o * n + D] = make_float2(gr, -gim);
         const float2 p = phi[b * D + o];                  // C[D][o] = conj(phi_o)
         const float dr = gr - p.x, di = gim + p.y;
         acc2 += 2.f * (dr * dr + di * di);
@@ -173,13 +174,13 @@ __global__ void vout_kernel(int n, const float *__restrict__ QV, const float *__
 }
 
 int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G,
-                   float *rn, float *w_out, const Ws &ws, hipStream_t st) {
+                   float *rn, float *w_out, const Ws &ws, hipStream_t st, bool lower_only) {
     ProfScope _prof(KC_REBUILD, st);
     if (nb <= 0) return ADMMNET_OK;
     const int n = D + 1;
     const size_t lds = sizeof(float) * (3 * ((n + 4) & ~3) + 2 * D + 8);
     hipLaunchKernelGGL(rebuild_kernel, dim3((unsigned)nb), dim3(RB_THREADS), lds, st, D, lw, ws.VT, ws.w,
-                       ws.w0, phi, h, G, rn);
+                       ws.w0, phi, h, G, rn, lower_only ? 1 : 0);
     ADMM_HIP(hipGetLastError());
     if (w_out) ADMM_HIP(hipMemcpyAsync(w_out, ws.w, sizeof(float) * nb * n, hipMemcpyDeviceToDevice, st));
     return ADMMNET_OK;

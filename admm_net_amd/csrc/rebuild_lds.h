@@ -38,7 +38,8 @@ __device__ __forceinline__ void rebuild_from_lds(const BrGeom &g, int64_t b, con
                                                  const float *VTl, const float *fs, const float *w0f,
                                                  const float *z0s, float *rowb, float *redb,
                                                  const float2 *__restrict__ phi, const float *__restrict__ h,
-                                                 float2 *__restrict__ G, float *__restrict__ rn, Mark mark) {
+                                                 float2 *__restrict__ G, float *__restrict__ rn, Mark mark,
+                                                 int lower_only = 0) {
     using f32x16 = __attribute__((ext_vector_type(16))) float;
     constexpr int BR_THREADS = 256;
     const int D = g.D, n = g.n, NT = g.NT, Dp = g.Dp, VP = g.VP;
@@ -127,7 +128,7 @@ __device__ __forceinline__ void rebuild_from_lds(const BrGeom &g, int64_t b, con
                     acc2 += d * d;
                 } else {
                     Gb[(int64_t)gi * n + gj] = make_float2(re, im);
-                    Gb[(int64_t)gj * n + gi] = make_float2(re, -im);
+                    if (!lower_only) Gb[(int64_t)gj * n + gi] = make_float2(re, -im);   // (state kept as lower triangle)
                     acc2 += 2.f * (re * re + im * im);
                 }
             }
@@ -146,7 +147,7 @@ __device__ __forceinline__ void rebuild_from_lds(const BrGeom &g, int64_t b, con
     for (int o = tid; o < D; o += BR_THREADS) {
         const float gr = rowb[o], gim = -rowb[Dp + o];     // G[D][o]
         Gb[(int64_t)D * n + o] = make_float2(gr, gim);
-        Gb[(int64_t)o * n + D] = make_float2(gr, -gim);
+        if (!lower_only) Gb[(int64_t)o * n + D] = make_float2(gr, -gim);
         const float2 p = phi[b * D + o];                   // C[D][o] = conj(phi_o)
         const float dr = gr - p.x, di = gim + p.y;
         acc2 += 2.f * (dr * dr + di * di);

@@ -247,7 +247,8 @@ static size_t td_lds_bytes(int D, bool ldsm) {
     return sz;
 }
 
-int launch_tridiag(int D, int64_t nb, const Ws &ws, hipStream_t st) {
+int launch_tridiag(int D, int64_t nb, const Ws &ws, hipStream_t st, const float2 *Zlow, const float2 *phi,
+                   const float *h, const float *lw) {
     ProfScope _prof(KC_TRIDIAG, st);
     if (D < 1 || D > kMaxD) {
         set_error("tridiag: D=%d unsupported (1..%d)", D, kMaxD);
@@ -264,7 +265,11 @@ int launch_tridiag(int D, int64_t nb, const Ws &ws, hipStream_t st) {
         const char *e = getenv("ADMMNET_TRIDIAG");
         use_lds = (e && !strcmp(e, "lds")) ? 1 : 0;
     }
-    if (D <= 128 && !use_lds) return launch_tridiag_reg(D, nb, ws, st);
+    if (D <= 128 && !use_lds) return launch_tridiag_reg(D, nb, ws, st, Zlow, phi, h, lw);
+    if (Zlow) {
+        set_error("tridiag: the lean loader exists for the register-resident kernel only (D <= 128)");
+        return ADMMNET_E_ARG;
+    }
     if (D <= 256 && !use_lds) return launch_tridiag_big(D, nb, ws, st);
     const bool ldsm = td_lds_bytes(D, true) <= 160 * 1024;
     const size_t lds = td_lds_bytes(D, ldsm);

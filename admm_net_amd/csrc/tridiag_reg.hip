@@ -311,11 +311,20 @@ struct TrPhases {
     }
 };
 
-template <int NA>
+// LEAN: the matrix A = C - Z / rho is formed HERE from the layer's own inputs -- the lower triangle of Z
+// (original index order, arrow row last), phi, h and two scalars -- instead of being read from an image that
+// the prep kernel would have to write first (A is Hermitian: 36 of the 64 register blocks are loaded, the
+// rest are their conjugate transposes, fetched from the owning threads through LDS).  Per signal and layer
+// this removes a 131 KB write and a 131 KB read of the image and halves the G / Z streams of the prep kernel.
+template <int NA, bool LEAN>
 __global__ __launch_bounds__(TR_THREADS, 2) void tridiag_reg_kernel(int D, float2 *__restrict__ Mbuf,
                                                                     float *__restrict__ QV,
                                                                     float *__restrict__ dT,
-                                                                    float *__restrict__ eT) {
+                                                                    float *__restrict__ eT,
+                                                                    const float2 *__restrict__ Zlow,
+                                                                    const float2 *__restrict__ phi,
+                                                                    const float *__restrict__ hvec,
+                                                                    const float *__restrict__ lw) {
     __shared__ TrShared<NA> sh;
     const int tid = threadIdx.x;
     const int tj = tid & 15, ti = tid >> 4;
@@ -327,15 +336,72 @@ __global__ __launch_bounds__(TR_THREADS, 2) void tridiag_reg_kernel(int D, float
     float *ecol = eT + bm * n;
 
     float2 m[NA][NA];
+    float corner;
+    if constexpr (LEAN) {
+        constexpr int NBLK = NA * (NA + 1) / 2, RB = (NBLK + 1) / 2;   // lower blocks, blocks per exchange round
+        __shared__ float2 xch[RB][16][17];
+        const float inv_rho = lw[S_INV_RHO_G], corner_g = lw[S_CORNER_G];
+        const float2 *Zm = Zlow + bm * (int64_t)n * n;
+        const float2 *ph = phi + bm * D;
+        const float *hh = hvec + bm * D;
 #pragma unroll
-    for (int a = 0; a < NA; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < NA; ++b) {
-            const int i = 16 * a + ti, j = 16 * b + tj;
-            m[a][b] = (i < D && j < D) ? Mg[(int64_t)i * D + j] : make_float2(0.f, 0.f);
+            for (int b = 0; b < NA; ++b) {
+                const int i = 16 * a + ti, j = 16 * b + tj;
+                float2 v = make_float2(0.f, 0.f);
+                if (b <= a && i < D && j < D && i >= j) {
+                    const float2 z = Zm[(int64_t)i * n + j];
+                    v = (i == j) ? make_float2(hh[i] - inv_rho * z.x, 0.f) : make_float2(-inv_rho * z.x, -inv_rho * z.y);
+                }
+                m[a][b] = v;
+            }
+        // arrow column a_i = phi_i - conj(Z[D][i]) / rho and the corner go through the image's arrow slot
+        if (tid < D) {
+            const float2 z = Zm[(int64_t)D * n + tid], p = ph[tid];
+            Mg[(int64_t)D * D + tid] = make_float2(p.x - inv_rho * z.x, p.y + inv_rho * z.y);
         }
-    const float corner = ag[D].x;
-    __syncthreads();   // all loads done before Mg rows are overwritten with reflectors
+        if (tid == 0) Mg[(int64_t)D * D + D] = make_float2(corner_g - inv_rho * Zm[(int64_t)D * n + D].x, 0.f);
+        // conjugate transposes of the lower blocks (and of the lower halves of the diagonal blocks)
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b <= a; ++b) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int blk = a * (a + 1) / 2 + b;
+                    if (blk / RB == round) xch[blk % RB][ti][tj] = m[a][b];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b <= a; ++b) {
+                    const int blk = a * (a + 1) / 2 + b;
+                    if (blk / RB == round) {
+                        const float2 t = xch[blk % RB][tj][ti];   // element (16 a + tj, 16 b + ti) of the lower block
+                        if (a != b) m[b][a] = make_float2(t.x, -t.y);
+                        else if (ti < tj) m[a][a] = make_float2(t.x, -t.y);
+                    }
+                }
+        }
+        __threadfence_block();
+        __syncthreads();   // arrow slot visible to the whole workgroup
+        corner = ag[D].x;
+    } else {
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < NA; ++b) {
+                const int i = 16 * a + ti, j = 16 * b + tj;
+                m[a][b] = (i < D && j < D) ? Mg[(int64_t)i * D + j] : make_float2(0.f, 0.f);
+            }
+        corner = ag[D].x;
+        __syncthreads();   // all loads done before Mg rows are overwritten with reflectors
+    }
 
     // ---------------- tridiagonalisation: reflector u has its unit entry at index u ----------
     TrPhases<NA, 0>::forward(m, sh, D, corner, ag, Mg, dcol, ecol);
@@ -380,24 +446,31 @@ __global__ __launch_bounds__(TR_THREADS, 2) void tridiag_reg_kernel(int D, float
 }
 
 template <int NA>
-static int launch_tr(int D, int64_t nb, const Ws &ws, hipStream_t st) {
-    hipLaunchKernelGGL(tridiag_reg_kernel<NA>, dim3((unsigned)nb), dim3(TR_THREADS), 0, st, D, ws.Mbuf, ws.QV,
-                       ws.dT, ws.eT);
+static int launch_tr(int D, int64_t nb, const Ws &ws, hipStream_t st, const float2 *Zlow, const float2 *phi,
+                     const float *h, const float *lw) {
+    if (Zlow)
+        hipLaunchKernelGGL((tridiag_reg_kernel<NA, true>), dim3((unsigned)nb), dim3(TR_THREADS), 0, st, D, ws.Mbuf,
+                           ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw);
+    else
+        hipLaunchKernelGGL((tridiag_reg_kernel<NA, false>), dim3((unsigned)nb), dim3(TR_THREADS), 0, st, D, ws.Mbuf,
+                           ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }
 
-int launch_tridiag_reg(int D, int64_t nb, const Ws &ws, hipStream_t st) {
+// Zlow != nullptr: "lean" loader (the kernel forms A = C - Z / rho itself, see tridiag_reg_kernel)
+int launch_tridiag_reg(int D, int64_t nb, const Ws &ws, hipStream_t st, const float2 *Zlow, const float2 *phi,
+                       const float *h, const float *lw) {
     const int na = (D + 15) / 16;
     switch (na) {
-        case 1: return launch_tr<1>(D, nb, ws, st);
-        case 2: return launch_tr<2>(D, nb, ws, st);
-        case 3: return launch_tr<3>(D, nb, ws, st);
-        case 4: return launch_tr<4>(D, nb, ws, st);
-        case 5: return launch_tr<5>(D, nb, ws, st);
-        case 6: return launch_tr<6>(D, nb, ws, st);
-        case 7: return launch_tr<7>(D, nb, ws, st);
-        case 8: return launch_tr<8>(D, nb, ws, st);
+        case 1: return launch_tr<1>(D, nb, ws, st, Zlow, phi, h, lw);
+        case 2: return launch_tr<2>(D, nb, ws, st, Zlow, phi, h, lw);
+        case 3: return launch_tr<3>(D, nb, ws, st, Zlow, phi, h, lw);
+        case 4: return launch_tr<4>(D, nb, ws, st, Zlow, phi, h, lw);
+        case 5: return launch_tr<5>(D, nb, ws, st, Zlow, phi, h, lw);
+        case 6: return launch_tr<6>(D, nb, ws, st, Zlow, phi, h, lw);
+        case 7: return launch_tr<7>(D, nb, ws, st, Zlow, phi, h, lw);
+        case 8: return launch_tr<8>(D, nb, ws, st, Zlow, phi, h, lw);
         default:
             set_error("tridiag_reg: D=%d unsupported", D);
             return ADMMNET_E_ARG;

@@ -38,6 +38,7 @@ VARIANTS = {
     "no_arrow": {"ADMMNET_ARROW": "0"},
     "unfused_back": {"ADMMNET_FUSE_BACK": "0", "ADMMNET_ARROW": "0"},
     "tridiag_lds": {"ADMMNET_TRIDIAG": "lds", "ADMMNET_ARROW": "0"},
+    "full_storage": {"ADMMNET_LEAN": "0"},
 }
 
 
