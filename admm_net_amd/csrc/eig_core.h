@@ -93,13 +93,30 @@ HD float recip_nr(float x) {
 #endif
 }
 
+// 1 / sqrt(x): v_rsq_f32 plus one Newton step on the device
+HD float rsqrt_nr1(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rsqf(x);
+    return r * fmaf(-0.5f * x * r, r, 1.5f);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+
 HD void householder_c(float ar, float ai, float xnorm2, float &beta, float &tr, float &ti,
                       float &sr, float &si) {
     if (xnorm2 == 0.f && ai == 0.f) {
         beta = ar; tr = 0.f; ti = 0.f; sr = 0.f; si = 0.f;
         return;
     }
-    float nrm = sqrtf(ar * ar + ai * ai + xnorm2);
+    const float q2 = ar * ar + ai * ai + xnorm2;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // sqrt through v_rsq_f32 + one Newton step (the IEEE sqrt sequence is ~15 dependent instructions on the
+    // serial path of every reflector); outside the safe exponent range the exact routine
+    float nrm = (q2 > 1e-30f && q2 < 1e30f) ? q2 * rsqrt_nr1(q2) : sqrtf(q2);
+#else
+    float nrm = sqrtf(q2);
+#endif
     beta = -sign_of(nrm, ar);
     const float ib = recip_nr(beta);
     tr = (beta - ar) * ib;

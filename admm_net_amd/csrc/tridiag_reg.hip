@@ -12,6 +12,8 @@
 // accumulated afterwards as P = Q^H (P <- P H^H), which puts ITS reduction on the fast lanes
 // too and needs no barrier at all.  Same mathematics as tridiag.hip / LAPACK chetd2 + cung2l
 // (first half of torch.linalg.eigh, /root/reference/admm_net.py:303).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace admmnet {
@@ -344,17 +346,25 @@ __global__ __launch_bounds__(TR_THREADS, 2) void tridiag_reg_kernel(int D, float
         const float2 *Zm = Zlow + bm * (int64_t)n * n;
         const float2 *ph = phi + bm * D;
         const float *hh = hvec + bm * D;
+        // all loads unconditional (clamped address, value selected afterwards): inside per-block branches
+        // every load waited for the previous one and the loader took 36 memory round trips
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
-            for (int b = 0; b < NA; ++b) {
+            for (int b = 0; b < NA; ++b) m[a][b] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
                 const int i = 16 * a + ti, j = 16 * b + tj;
-                float2 v = make_float2(0.f, 0.f);
-                if (b <= a && i < D && j < D && i >= j) {
-                    const float2 z = Zm[(int64_t)i * n + j];
-                    v = (i == j) ? make_float2(hh[i] - inv_rho * z.x, 0.f) : make_float2(-inv_rho * z.x, -inv_rho * z.y);
+                const bool ok = i < D && j < D && i >= j;
+                const float2 z = Zm[ok ? (int64_t)i * n + j : 0];
+                float2 v = make_float2(-inv_rho * z.x, -inv_rho * z.y);
+                if (a == b) {   // diagonal block: h on the diagonal, which is real
+                    const float hv = hh[min(i, D - 1)];
+                    if (ti == tj) v = make_float2(hv + v.x, 0.f);
                 }
-                m[a][b] = v;
+                m[a][b] = ok ? v : make_float2(0.f, 0.f);
             }
         // arrow column a_i = phi_i - conj(Z[D][i]) / rho and the corner go through the image's arrow slot
         if (tid < D) {
@@ -448,11 +458,20 @@ __global__ __launch_bounds__(TR_THREADS, 2) void tridiag_reg_kernel(int D, float
 template <int NA>
 static int launch_tr(int D, int64_t nb, const Ws &ws, hipStream_t st, const float2 *Zlow, const float2 *phi,
                      const float *h, const float *lw) {
+    // developer knob: ADMMNET_TR_PAD_LDS=<bytes> of unused dynamic LDS per workgroup (e.g. 100000 leaves one
+    // workgroup per CU: tells latency-bound from issue-bound)
+    static const int pad = getenv("ADMMNET_TR_PAD_LDS") ? atoi(getenv("ADMMNET_TR_PAD_LDS")) : 0;
+    if (pad > 0) {
+        ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_reg_kernel<NA, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+        ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_reg_kernel<NA, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+    }
     if (Zlow)
-        hipLaunchKernelGGL((tridiag_reg_kernel<NA, true>), dim3((unsigned)nb), dim3(TR_THREADS), 0, st, D, ws.Mbuf,
+        hipLaunchKernelGGL((tridiag_reg_kernel<NA, true>), dim3((unsigned)nb), dim3(TR_THREADS), pad, st, D, ws.Mbuf,
                            ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw);
     else
-        hipLaunchKernelGGL((tridiag_reg_kernel<NA, false>), dim3((unsigned)nb), dim3(TR_THREADS), 0, st, D, ws.Mbuf,
+        hipLaunchKernelGGL((tridiag_reg_kernel<NA, false>), dim3((unsigned)nb), dim3(TR_THREADS), pad, st, D, ws.Mbuf,
                            ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
