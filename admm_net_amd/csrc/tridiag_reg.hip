@@ -154,18 +154,21 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
     const float2 alpha = sh.head[par];
     float beta, tr, tim, sr, si;
     householder_c(alpha.x, alpha.y, xn2, beta, tr, tim, sr, si);
-    const float2 tau = make_float2(tr, tim), sc = make_float2(sr, si);
+    // UNNORMALISED reflector: H = I - tau v v^H with v = s u, u = (alpha - beta at the unit position, x below)
+    // is the same operator as I - gamma u u^H, gamma = tau |s|^2.  Working with (gamma, u) saves the scaling of
+    // every vector entry in both passes (x is already in LDS / memory; only the head changes).
+    const float g2 = sr * sr + si * si;
+    const float2 tau = make_float2(tr * g2, tim * g2);
+    const v2 hu = v2{alpha.x - beta, alpha.y};
     if (tid == 0) {
         ecol[u] = beta;
         dcol[u] = (u == 0) ? corner : sh.dprev[par];
         sh.taus[u] = tau;
     }
-    // v = scale * x, one at the unit position (x is already zero above it and beyond D)
-    const v2 scv = tov2(sc), scj = rot(scv);
     // keep the reflector for the Q accumulation: row u of the (consumed) global image
     if (tid < D) {
-        v2 x = pk_cmac(v2{0.f, 0.f}, tov2(col[tid]), scv, scj);
-        if (tid == u) x = v2{1.f, 0.f};
+        v2 x = tov2(col[tid]);
+        if (tid == u) x = hu;
         Mg[(int64_t)u * D + tid] = tof2(x);
     }
     if (tr == 0.f && tim == 0.f) return;   // H = I (uniform)
@@ -173,11 +176,11 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
     v2 vr[NA], vc[NA];
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
-        vr[a] = pk_cmac(v2{0.f, 0.f}, tov2(col[16 * a + ti]), scv, scj);
-        vc[a] = pk_cmac(v2{0.f, 0.f}, tov2(col[16 * a + tj]), scv, scj);
+        vr[a] = tov2(col[16 * a + ti]);
+        vc[a] = tov2(col[16 * a + tj]);
         if (a == A0) {   // the unit position can only sit in the first active block
-            if (16 * a + ti == u) vr[a] = v2{1.f, 0.f};
-            if (16 * a + tj == u) vc[a] = v2{1.f, 0.f};
+            if (16 * a + ti == u) vr[a] = hu;
+            if (16 * a + tj == u) vc[a] = hu;
         }
     }
     const v2 vcj = rot(vc[NA - 1]);
