@@ -19,7 +19,9 @@ HEADERS = ["common.h", "eig_core.h", "dc_core.h", "arrow_core.h", "rebuild_lds.h
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-file extras: the SLP vectoriser packs the rotation replay into v_pk_* ops that need a
 # register shuffle per plane (7 VALU per rotation instead of 4)
-EXTRA_FLAGS = {"rotapply.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"rotapply.hip": ["-fno-slp-vectorize"],
+               # here the SLP pass re-packs the DPP reduction adds into v_mov_dpp + v_pk_add (3 instructions for 2)
+               "tridiag_reg.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -199,7 +199,7 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
     v2 dotp = {0.f, 0.f}, psel = {0.f, 0.f};
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
-        pr[a] = pk_cmac(v2{0.f, 0.f}, pr[a], tauv, tauj);   // tau * acc
+        pr[a] = pk_cmac_sel(v2{0.f, 0.f}, pr[a], tauv);   // tau * acc
         // conj(p) v = v.x (p.x, -p.y) + v.y (p.y, p.x); every lane of the 16 adds the same term,
         // the total is scaled by 1/16 below (exact)
         dotp = __builtin_elementwise_fma(vr[a].xx, v2{pr[a].x, -pr[a].y}, dotp);
@@ -225,14 +225,14 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
 #pragma unroll
     for (int b = A0; b < NA; ++b) {
         const int j = 16 * b + tj;
-        v2 w = pk_cmac(tov2(sh.pbuf[par][j]), vc[b], alv, alj);   // p_j + alpha v_j
+        v2 w = pk_cmac_sel(tov2(sh.pbuf[par][j]), vc[b], alv);   // p_j + alpha v_j
         if (b == A0) w = (j >= u) ? w : v2{0.f, 0.f};
         wc[b] = w;
     }
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
         const int i = 16 * a + ti;
-        v2 w = pk_cmac(pr[a], vr[a], alv, alj);   // p_i + alpha v_i
+        v2 w = pk_cmac_sel(pr[a], vr[a], alv);   // p_i + alpha v_i
         if (a == A0) w = (i >= u) ? w : v2{0.f, 0.f};
         const v2 wra = -w;
         const v2 vra = -vr[a];
@@ -290,7 +290,7 @@ __device__ __forceinline__ void q_step(float2 (&m)[NA][NA], const TrShared<NA> &
         const v2 nct = v2{-tau.x, tau.y}, nctj = rot(nct);   // -conj(tau)
 #pragma unroll
         for (int a = A0; a < NA; ++a) {
-            const v2 nty = pk_cmac(v2{0.f, 0.f}, y[a], nct, nctj);
+            const v2 nty = pk_cmac_sel(v2{0.f, 0.f}, y[a], nct);
 #pragma unroll
             for (int b = A0; b < NA; ++b) m[a][b] = tof2(pk_cmacc_sel(tov2(m[a][b]), nty, vc[b]));   // -= conj(tau) y conj(v_b)
         }
