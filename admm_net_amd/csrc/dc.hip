@@ -198,11 +198,8 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         }
         __syncthreads();
         mark(2);
-        // P2: deflation scan (one thread per merge).  Which wave of a large team runs this serial chain rotates
-        //     with the workgroup index: with always-wave-0 the SIMD that hosts wave 0 of every co-resident
-        //     workgroup carries all the scans of the CU.
-        const int scan_lane = (ts >= 128) ? 64 * (int)(bm % (ts / 64)) : 0;
-        if (act && tl == scan_lane) {
+        // P2: deflation scan (one thread per merge)
+        if (act && tl == 0) {
             int k = 0, nr = 0;
             deflate_scan_tol(nn, rho, __int_as_float(sh.mx[team][0]), __int_as_float(sh.mx[team][1]), ds + a, zs + a,
                              dl + a, zl + a, src + a, rot + a, k, nr);

@@ -155,7 +155,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    lib.admmnet_profile_enable(1)
+    lib.admmnet_profile_enable(0 if os.environ.get("ADMMNET_BENCH_NOPROF") else 1)   # (developer: cost of the event pairs)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
