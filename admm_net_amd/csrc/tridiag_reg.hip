@@ -82,6 +82,23 @@ __device__ __forceinline__ v2 pk_cmacc_sel(v2 acc, v2 a, v2 b) {
         : "v"(a), "v"(b));
     return acc;
 }
+// m * v (no accumulator to clear first)
+__device__ __forceinline__ v2 pk_cmul_sel(v2 m, v2 v) {
+    v2 acc;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(acc)
+        : "v"(m), "v"(v));
+    return acc;
+}
+// acc - a * conj(b): the same pair with the broadcast operand negated (neg_lo / neg_hi on src0)
+__device__ __forceinline__ v2 pk_cmsubc_sel(v2 acc, v2 a, v2 b) {
+    asm("v_pk_fma_f32 %0, %2, %1, %0 op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,1,0]"
+        : "+v"(acc)
+        : "v"(a), "v"(b));
+    return acc;
+}
 // stage-wise row reduction of NA complex values: the NA chains interleave, so no DPP hazard stalls
 template <int NA, int A0>
 __device__ __forceinline__ void row16_sum_all(v2 (&acc)[NA]) {
@@ -189,21 +206,29 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
     v2 pr[NA];
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
-        v2 acc = {0.f, 0.f};
+        if constexpr (A0 < NA - 1) {
+            v2 acc = pk_cmul_sel(tov2(m[a][A0]), vc[A0]);
 #pragma unroll
-        for (int b = A0; b < NA - 1; ++b) acc = pk_cmac_sel(acc, tov2(m[a][b]), vc[b]);
-        pr[a] = pk_cmac(acc, tov2(m[a][NA - 1]), vc[NA - 1], vcj);   // last term by the compiler (DPP reads pr next)
+            for (int b = A0 + 1; b < NA - 1; ++b) acc = pk_cmac_sel(acc, tov2(m[a][b]), vc[b]);
+            pr[a] = pk_cmac(acc, tov2(m[a][NA - 1]), vc[NA - 1], vcj);   // last term by the compiler (DPP reads pr next)
+        } else {
+            pr[a] = pk_cmac(v2{0.f, 0.f}, tov2(m[a][NA - 1]), vc[NA - 1], vcj);
+        }
     }
     row16_sum_all<NA, A0>(pr);
     const v2 tauv = tov2(tau), tauj = rot(tauv);
     v2 dotp = {0.f, 0.f}, psel = {0.f, 0.f};
 #pragma unroll
     for (int a = A0; a < NA; ++a) {
-        pr[a] = pk_cmac_sel(v2{0.f, 0.f}, pr[a], tauv);   // tau * acc
+        pr[a] = pk_cmul_sel(pr[a], tauv);   // tau * acc
         // conj(p) v = v.x (p.x, -p.y) + v.y (p.y, p.x); every lane of the 16 adds the same term,
         // the total is scaled by 1/16 below (exact)
-        dotp = __builtin_elementwise_fma(vr[a].xx, v2{pr[a].x, -pr[a].y}, dotp);
-        dotp = __builtin_elementwise_fma(vr[a].yy, v2{pr[a].y, pr[a].x}, dotp);
+        if (a < NA - 1) {
+            dotp = pk_cmacc_sel(dotp, vr[a], pr[a]);   // + v_i conj(p_i)
+        } else {   // last term by the compiler (DPP reads dotp next)
+            dotp = __builtin_elementwise_fma(vr[a].xx, v2{pr[a].x, -pr[a].y}, dotp);
+            dotp = __builtin_elementwise_fma(vr[a].yy, v2{pr[a].y, pr[a].x}, dotp);
+        }
         psel = (tj == a) ? pr[a] : psel;
     }
     if (tj >= A0 && tj < NA) sh.pbuf[par][16 * tj + ti] = tof2(psel);   // lane a of a row publishes p of block row a
@@ -234,13 +259,13 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
         const int i = 16 * a + ti;
         v2 w = pk_cmac_sel(pr[a], vr[a], alv);   // p_i + alpha v_i
         if (a == A0) w = (i >= u) ? w : v2{0.f, 0.f};
-        const v2 wra = -w;
-        const v2 vra = -vr[a];
+        const v2 wra = w;
+        const v2 vra = vr[a];
 #pragma unroll
         for (int b = A0; b < NA; ++b) {
             v2 x = tov2(m[a][b]);
-            x = pk_cmacc_sel(x, vra, wc[b]);
-            x = pk_cmacc_sel(x, wra, vc[b]);
+            x = pk_cmsubc_sel(x, vra, wc[b]);
+            x = pk_cmsubc_sel(x, wra, vc[b]);
             if (a == b && ti == tj) x.y = 0.f;
             m[a][b] = tof2(x);
         }
@@ -281,16 +306,20 @@ __device__ __forceinline__ void q_step(float2 (&m)[NA][NA], const TrShared<NA> &
         const v2 vjl = rot(vc[NA - 1]);
 #pragma unroll
         for (int a = A0; a < NA; ++a) {
-            v2 acc = {0.f, 0.f};
+            if constexpr (A0 < NA - 1) {
+                v2 acc = pk_cmul_sel(tov2(m[a][A0]), vc[A0]);
 #pragma unroll
-            for (int b = A0; b < NA - 1; ++b) acc = pk_cmac_sel(acc, tov2(m[a][b]), vc[b]);
-            y[a] = pk_cmac(acc, tov2(m[a][NA - 1]), vc[NA - 1], vjl);   // last term by the compiler (DPP reads y next)
+                for (int b = A0 + 1; b < NA - 1; ++b) acc = pk_cmac_sel(acc, tov2(m[a][b]), vc[b]);
+                y[a] = pk_cmac(acc, tov2(m[a][NA - 1]), vc[NA - 1], vjl);   // last term by the compiler (DPP reads y next)
+            } else {
+                y[a] = pk_cmac(v2{0.f, 0.f}, tov2(m[a][NA - 1]), vc[NA - 1], vjl);
+            }
         }
         row16_sum_all<NA, A0>(y);
         const v2 nct = v2{-tau.x, tau.y}, nctj = rot(nct);   // -conj(tau)
 #pragma unroll
         for (int a = A0; a < NA; ++a) {
-            const v2 nty = pk_cmac_sel(v2{0.f, 0.f}, y[a], nct);
+            const v2 nty = pk_cmul_sel(y[a], nct);
 #pragma unroll
             for (int b = A0; b < NA; ++b) m[a][b] = tof2(pk_cmacc_sel(tov2(m[a][b]), nty, vc[b]));   // -= conj(tau) y conj(v_b)
         }
