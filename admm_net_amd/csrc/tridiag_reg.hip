@@ -14,6 +14,8 @@
 // (first half of torch.linalg.eigh, /root/reference/admm_net.py:303).
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace admmnet {
@@ -41,6 +43,18 @@ __device__ __forceinline__ float wave_sum_dpp(float x) {
     x += dpp_get<0x142, 0xA>(x);   // rows 1, 3 += row 0, 2
     x += dpp_get<0x143, 0xC>(x);   // rows 2, 3 += rows 0 + 1
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
+// two wave sums at once: the chains interleave, so no DPP hazard stalls between dependent steps
+__device__ __forceinline__ void wave_sum_dpp2(float &x, float &y) {
+    x += dpp_get<0x128>(x); y += dpp_get<0x128>(y);
+    x += dpp_get<0x124>(x); y += dpp_get<0x124>(y);
+    x += dpp_get<0x122>(x); y += dpp_get<0x122>(y);
+    x += dpp_get<0x121>(x); y += dpp_get<0x121>(y);
+    x += dpp_get<0x142, 0xA>(x); y += dpp_get<0x142, 0xA>(y);
+    x += dpp_get<0x143, 0xC>(x); y += dpp_get<0x143, 0xC>(y);
+    x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+    y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), 63));
 }
 
 // Complex arithmetic on (re, im) register pairs written so that hipcc emits ONE v_pk_fma_f32 per
@@ -145,15 +159,19 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
         if (tj == (k & 15)) {
             // column k lives in block (k >> 4), which is A0 or (for u = 16 A0) A0 - 1
             constexpr int AP = A0 > 0 ? A0 - 1 : 0;
-            const bool cur = (k >> 4) == A0;
+            auto publish = [&](auto blk) {   // blk: compile-time column block holding column k
+                constexpr int B = decltype(blk)::value;
 #pragma unroll
-            for (int a = AP; a < NA; ++a) {
-                const int i = 16 * a + ti;
-                const float2 x = cur ? m[a][A0] : m[a][AP];
-                sh.colbuf[par][i] = (i > u) ? x : make_float2(0.f, 0.f);
-                if (i == u) sh.head[par] = x;
-                if (i == k) sh.dprev[par] = x.x;
-            }
+                for (int a = AP; a < NA; ++a) {
+                    const int i = 16 * a + ti;
+                    const float2 x = m[a][B];
+                    sh.colbuf[par][i] = (i > u) ? x : make_float2(0.f, 0.f);
+                    if (i == u) sh.head[par] = x;
+                    if (i == k) sh.dprev[par] = x.x;
+                }
+            };
+            if ((k >> 4) == A0) publish(std::integral_constant<int, A0>{});   // (uniform branch: no per-entry selects)
+            else publish(std::integral_constant<int, AP>{});
         }
     }
     __syncthreads();   // (A) column visible
@@ -232,8 +250,11 @@ __device__ __forceinline__ void tr_step(float2 (&m)[NA][NA], TrShared<NA> &sh, i
         psel = (tj == a) ? pr[a] : psel;
     }
     if (tj >= A0 && tj < NA) sh.pbuf[par][16 * tj + ti] = tof2(psel);   // lane a of a row publishes p of block row a
-    dotp.x = wave_sum_dpp(dotp.x);
-    dotp.y = wave_sum_dpp(dotp.y);
+    {
+        float dx = dotp.x, dy = dotp.y;
+        wave_sum_dpp2(dx, dy);
+        dotp = v2{dx, dy};
+    }
     if (lane == 0) sh.dotbuf[par][wave] = make_float2(dotp.x * 0.0625f, dotp.y * 0.0625f);
     __syncthreads();   // (B) p and the dot partials visible
     float2 dot = sh.dotbuf[par][0];
