@@ -46,7 +46,9 @@ __device__ __forceinline__ v2 b_cmacc(v2 acc, v2 a, v2 aj, v2 b) {   // acc + a 
 
 template <int NA>
 struct TbShared {
-    float2 colbuf[2][32 * NA];
+    float2 colbuf[2][32 * NA];   // x = column below the unit position, ZERO at i <= u and i >= D
+    float2 head[2];              // alpha = column entry at the unit position
+    float dprev[2];              // finished diagonal entry d[u]
     float2 prow[32 * NA];
     float2 pfull[32 * NA];
     float2 cpart[16][32 * (NA - 1)];
@@ -73,40 +75,52 @@ __device__ __forceinline__ void tb_step(float2 (&m)[tb_nslot(NA)], float2 *__res
     const int tj = tid & 31, ti = tid >> 5;
     const int par = u & 1;
     if (u == 0) {
-        for (int i = tid; i < 32 * NA; i += TB_THREADS) sh.colbuf[0][i] = (i < D) ? Mg[(int64_t)D * D + i] : make_float2(0.f, 0.f);
+        for (int i = tid; i < 32 * NA; i += TB_THREADS) {
+            const float2 x = (i < D) ? Mg[(int64_t)D * D + i] : make_float2(0.f, 0.f);
+            sh.colbuf[0][i] = (i > 0) ? x : make_float2(0.f, 0.f);
+            if (i == 0) sh.head[0] = x;
+        }
     } else {
         const int k = u - 1;
         if (tj == (k & 31)) {
+            auto put = [&](int a, float2 x) {
+                const int i = 32 * a + ti;
+                sh.colbuf[par][i] = (i > u) ? x : make_float2(0.f, 0.f);
+                if (i == u) sh.head[par] = x;
+                if (i == k) sh.dprev[par] = x.x;
+            };
             if ((k >> 5) == A0) {
 #pragma unroll
-                for (int a = A0; a < NA; ++a) sh.colbuf[par][32 * a + ti] = TB_GET(a, A0);
+                for (int a = A0; a < NA; ++a) put(a, TB_GET(a, A0));
             } else {
                 constexpr int B = A0 > 0 ? A0 - 1 : 0;
 #pragma unroll
-                for (int a = B; a < NA; ++a) sh.colbuf[par][32 * a + ti] = TB_GET(a, B);
+                for (int a = B; a < NA; ++a) put(a, TB_GET(a, B));
             }
         }
     }
     __syncthreads();   // (A)
     const float2 *col = sh.colbuf[par];
     float pn = 0.f;
-    for (int i = u + 1 + lane; i < D; i += 64) {
+    for (int i = lane; i < 32 * NA; i += 64) {
         const float2 x = col[i];
         pn += x.x * x.x + x.y * x.y;
     }
     const float xn2 = wave_sum(pn);
-    const float2 alpha = col[u];
+    const float2 alpha = sh.head[par];
     float beta, tr, tim, sr, si;
     householder_c(alpha.x, alpha.y, xn2, beta, tr, tim, sr, si);
-    const float2 tau = make_float2(tr, tim), sc = make_float2(sr, si);
-    auto vat = [&](int i) -> float2 {   // component i of the reflector (zero above the unit entry / beyond D)
-        float2 x = (i > u && i < D) ? cmul(col[i], sc) : make_float2(0.f, 0.f);
-        if (i == u) x = make_float2(1.f, 0.f);
-        return x;
+    // UNNORMALISED reflector (as in tridiag_reg.hip): H = I - tau v v^H with v = s u is I - gamma u u^H,
+    // gamma = tau |s|^2, u = (alpha - beta at the unit position, x below): no per-entry scaling anywhere
+    const float g2 = sr * sr + si * si;
+    const float2 tau = make_float2(tr * g2, tim * g2);
+    const float2 hu = make_float2(alpha.x - beta, alpha.y);
+    auto vat = [&](int i) -> float2 {   // component i of the reflector (the column buffer is zero above the unit entry / beyond D)
+        return (i == u) ? hu : col[i];
     };
     if (tid == 0) {
         ecol[u] = beta;
-        dcol[u] = (u == 0) ? corner : col[u - 1].x;
+        dcol[u] = (u == 0) ? corner : sh.dprev[par];
     }
     if (tid < D) Mg[(int64_t)u * D + tid] = vat(tid);          // reflector row u for the Q kernel
     if (tid == 0) Mg[(int64_t)D * D + u] = tau;                 // taus live in the consumed arrow slot
