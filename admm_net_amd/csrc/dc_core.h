@@ -167,24 +167,19 @@ HD void deflate_scan_tol(int nn, float rho, float dmax, float zmax, FA ds, FA zs
     }
     int pj = -1;
     float dpj = 0.f, zpj = 0.f;
-    float dn = ds[0], zn = zs[0];
-    for (int j = 0; j < nn; ++j) {
-        const float dj = dn, zj = zn;
-        if (j + 1 < nn) {
-            dn = ds[j + 1];
-            zn = zs[j + 1];
-        }
+    // one scan step on (j, d_j, z_j)
+    auto step = [&](int j, float dj, float zj) {
         if (rho * fabsf(zj) <= tol) {   // type 1: tiny z component
             --k2;
             dl[k2] = dj;
             src[k2] = j;
-            continue;
+            return;
         }
         if (pj < 0) {
             pj = j;
             dpj = dj;
             zpj = zj;
-            continue;
+            return;
         }
         // type 2: two (nearly) equal poles -> rotate z_pj into z_j.  With c = z_j / tau, s = -z_pj / tau
         // the test |t c s| <= tol reads |t z_j z_pj| <= tol tau^2: no square root unless it deflates.
@@ -198,25 +193,46 @@ HD void deflate_scan_tol(int nn, float rho, float dmax, float zmax, FA ds, FA zs
             pj = j;
             dpj = dj;
             zpj = zj;
-            continue;
+            return;
         }
         const float itau = rsqrt_nr(q);
         const float tau = q * itau;
         const float c = zj * itau, s = -zpj * itau;
-        {
-            DcRot r;
-            r.pa = pj;
-            r.pb = j;
-            r.c = c;
-            r.s = s;
-            rot[nrot++] = r;
-            --k2;
-            dl[k2] = dpj * c * c + dj * s * s;
-            src[k2] = pj;
-            dpj = dpj * s * s + dj * c * c;
-            zpj = tau;
-            pj = j;
+        DcRot r;
+        r.pa = pj;
+        r.pb = j;
+        r.c = c;
+        r.s = s;
+        rot[nrot++] = r;
+        --k2;
+        dl[k2] = dpj * c * c + dj * s * s;
+        src[k2] = pj;
+        dpj = dpj * s * s + dj * c * c;
+        zpj = tau;
+        pj = j;
+    };
+    // The inputs are read four entries at a time, one group ahead of their use (two register sets in
+    // ping-pong): with a one-step look-ahead the copy "next -> current" at the end of every trip still waited
+    // for the load it had just issued.
+    float da[4], za[4], db[4], zb[4];
+    auto fetch = [&](int j0, float (&d4)[4], float (&z4)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = (j0 + q < nn) ? j0 + q : nn - 1;
+            d4[q] = ds[j];
+            z4[q] = zs[j];
         }
+    };
+    fetch(0, da, za);
+    for (int j0 = 0; j0 < nn; j0 += 8) {
+        fetch(j0 + 4, db, zb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (j0 + q < nn) step(j0 + q, da[q], za[q]);
+        fetch(j0 + 8, da, za);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (j0 + 4 + q < nn) step(j0 + 4 + q, db[q], zb[q]);
     }
     if (pj >= 0) {
         dl[k] = dpj;
