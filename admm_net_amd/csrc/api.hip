@@ -180,8 +180,11 @@ static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream
     int rc;
     if ((rc = launch_tridiag(D, nb, ws, st, Zlow, phi, h, lw))) return rc;
     if (ws.Wdc) {   // divide & conquer + V = Q W on the matrix cores
-        if ((rc = launch_dc(D + 1, nb, ws, status, st, with_v))) return rc;   // fused consumer reads WT itself
-        return with_v ? launch_vgemm(D, nb, ws, st) : ADMMNET_OK;
+        // the fused consumer (backrebuild.hip) and the large back-transform read the transposed image WT themselves
+        const bool big = vgemm_big_supported(D);
+        if ((rc = launch_dc(D + 1, nb, ws, status, st, with_v && !big))) return rc;
+        if (!with_v) return ADMMNET_OK;
+        return big ? launch_vgemm_big(D, nb, ws, st) : launch_vgemm(D, nb, ws, st);
     }
     if ((rc = launch_tql(D + 1, nb, ws, status, st))) return rc;
     return launch_rotapply(D, nb, ws, st);

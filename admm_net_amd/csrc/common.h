@@ -130,6 +130,8 @@ int launch_rotapply(int D, int64_t nb, const Ws &ws, hipStream_t st);
 int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool rowmajor = true);   // dc.hip
 int64_t dc_final_offset(int n);                                                            // dc.hip
 int launch_vgemm(int D, int64_t nb, const Ws &ws, hipStream_t st);                       // dc.hip
+bool vgemm_big_supported(int D);                                                          // vgemm_big.hip
+int launch_vgemm_big(int D, int64_t nb, const Ws &ws, hipStream_t st);                   // vgemm_big.hip (reads WT)
 int launch_peaks(const float2 *phi, int64_t B, int xbase, int ybase, const double *Z, int nx, int ny,
                  const double *axis_x, const double *axis_y, const double *opt7, int iters, int max_peaks,
                  double *peaks, int32_t *counts, hipStream_t st);                          // peaks.hip

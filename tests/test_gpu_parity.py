@@ -48,7 +48,7 @@ def rel(a, b):
 
 
 # ------------------------------------------------------------------ building blocks
-@pytest.mark.parametrize("n", [2, 3, 10, 17, 65, 101, 129, 200, 257])
+@pytest.mark.parametrize("n", [2, 3, 10, 17, 65, 101, 129, 130, 169, 200, 229, 256, 257])
 def test_eigh_block(dev, n):
     rng = np.random.default_rng(n)
     X = rng.standard_normal((6, n, n)) + 1j * rng.standard_normal((6, n, n))
