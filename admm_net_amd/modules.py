@@ -7,7 +7,11 @@ return values and the same ``state_dict`` key set / parameter names
 below are parameter containers registered in the reference's order (so
 ``torch.manual_seed(s)`` + construction yields the reference's initial
 weights); all arithmetic happens in the fused HIP path behind the C ABI of
-``include/admmnet.h``.  Forward only: there is no CPU or eager fallback.
+``include/admmnet.h``.  There is no CPU or eager fallback.
+
+Inference (``.eval()`` or ``torch.no_grad()``) runs the fused forward.  In train mode with gradients
+enabled the call goes through ``training.unrolled_forward`` instead: differentiable tensor operations
+around the HIP eigensolver, with the reference's eigenvalue-only gradient.
 """
 from __future__ import annotations
 
@@ -210,10 +214,6 @@ class _FusedBase(nn.Module):
         return torch.device("cuda", torch.cuda.current_device())
 
     def _run(self, y, b, sigma):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError(
-                "training (backward through the unrolled layers) is not implemented in the HIP path; "
-                "call .eval() for inference (SURVEY.md section 8f, rank 2)")
         lib = _lib.load()
         dev = self._compute_device(y)
         D = self.M * self.N
@@ -247,11 +247,33 @@ class _FusedBase(nn.Module):
         return phi, head
 
 
+    # ---- training ----------------------------------------------------------
+    def forward_autograd(self, y, b, sigma):
+        """Differentiable forward (what ``forward`` does in train mode); usable in eval mode too, e.g. to
+        take gradients without the attention dropout.  The parameters must live on the GPU."""
+        from . import training
+        _lib.load()                                   # fail loudly without the HIP library
+        dev = self._compute_device(y)
+        pdev = next(self.parameters()).device
+        if pdev != dev:
+            raise _lib.AdmmNetError(f"training runs on the GPU: parameters are on {pdev}, expected {dev} "
+                                    "(move the model with .to(device) as train.py / trainPhi.py do)")
+        out = training.unrolled_forward(self, y.to(dev), b.to(dev), sigma.to(dev))
+        if isinstance(out, tuple):
+            return tuple(o.to(y.device) for o in out)
+        return out.to(y.device)
+
+    def _wants_grad(self) -> bool:
+        return self.training and torch.is_grad_enabled()
+
+
 class PhiEstADMMNet(_FusedBase):
     """admm_net.py:724-764: K unrolled ADMM layers, returns phi [B, M*N] complex64."""
     _HAS_HEAD = False
 
     def forward(self, y, b, sigma):
+        if self._wants_grad():
+            return self.forward_autograd(y, b, sigma)
         phi, _ = self._run(y, b, sigma)
         return phi
 
@@ -261,5 +283,7 @@ class ADMMNet(_FusedBase):
     _HAS_HEAD = True
 
     def forward(self, y, b, sigma):
+        if self._wants_grad():
+            return self.forward_autograd(y, b, sigma)
         phi, head = self._run(y, b, sigma)
         return head[0], head[1], head[2], phi

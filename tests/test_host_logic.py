@@ -94,12 +94,6 @@ def test_forward_without_gpu_fails_loudly():
         m(torch.zeros(1, 9, dtype=torch.complex64), torch.ones(1, 9, dtype=torch.complex64), torch.ones(1))
 
 
-def test_training_mode_is_refused():
-    m = A.PhiEstADMMNet(M=3, N=3, num_layers=2)      # .train() by default
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 9, dtype=torch.complex64), torch.ones(1, 9, dtype=torch.complex64), torch.ones(1))
-
-
 def test_product_never_imports_oracle():
     for path in glob.glob(os.path.join(ROOT, "admm_net_amd", "*.py")):
         src = open(path).read()
