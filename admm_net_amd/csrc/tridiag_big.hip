@@ -270,9 +270,10 @@ __global__ __launch_bounds__(TB_THREADS) void tridiag_big_kernel(int D, float2 *
     }
 }
 
-// P = Q^H, rows [128 g, 128 g + 128) handled by workgroup g:  P <- P (I - conj(tau_u) v_u v_u^H), u = D-1 .. 0.
+// P = Q^H, the 32-row blocks {g, g + 2, g + 4, g + 6} handled by workgroup g (interleaved: the work per row grows
+// with the row index):  P <- P (I - conj(tau_u) v_u v_u^H), u = D-1 .. 0.
 template <int NB, int B0>
-__device__ __forceinline__ void ub_step(float2 (&p)[4][NB], int u, int D, const float2 *__restrict__ Mg) {
+__device__ __forceinline__ void ub_step(float2 (&p)[4][NB], int u, int D, const float2 *__restrict__ Mg, int g) {
     const int tj = threadIdx.x & 31;
     const float2 tau = Mg[(int64_t)D * D + u];
     if (tau.x == 0.f && tau.y == 0.f) return;
@@ -286,6 +287,9 @@ __device__ __forceinline__ void ub_step(float2 (&p)[4][NB], int u, int D, const 
     const float2 ctau = make_float2(tau.x, -tau.y);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
+        // row r of P is still e_r while u > r (v_u vanishes above its unit entry): row blocks above the
+        // reflector's block have nothing to do (uniform per workgroup)
+        if (2 * a + g < B0) continue;
         v2 y = {0.f, 0.f};
 #pragma unroll
         for (int b = B0; b < NB; ++b) y = b_cmac(y, b_tov2(p[a][b]), vc[b], vj[b]);
@@ -300,10 +304,10 @@ __device__ __forceinline__ void ub_step(float2 (&p)[4][NB], int u, int D, const 
 
 template <int NB, int B0>
 struct UbPhases {
-    static __device__ __forceinline__ void run(float2 (&p)[4][NB], int D, const float2 *Mg) {
-        if constexpr (B0 + 1 < NB) UbPhases<NB, B0 + 1>::run(p, D, Mg);
+    static __device__ __forceinline__ void run(float2 (&p)[4][NB], int D, const float2 *Mg, int g) {
+        if constexpr (B0 + 1 < NB) UbPhases<NB, B0 + 1>::run(p, D, Mg, g);
         const int hi = min(32 * (B0 + 1), D);
-        for (int u = hi - 1; u >= 32 * B0; --u) ub_step<NB, B0>(p, u, D, Mg);
+        for (int u = hi - 1; u >= 32 * B0; --u) ub_step<NB, B0>(p, u, D, Mg, g);
     }
 };
 
@@ -320,14 +324,14 @@ __global__ __launch_bounds__(TB_THREADS) void ungtr_big_kernel(int D, const floa
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) p[a][b] = make_float2((128 * g + 32 * a + ti == 32 * b + tj) ? 1.f : 0.f, 0.f);
-    UbPhases<NB, 0>::run(p, D, Mg);
+        for (int b = 0; b < NB; ++b) p[a][b] = make_float2((32 * (2 * a + g) + ti == 32 * b + tj) ? 1.f : 0.f, 0.f);
+    UbPhases<NB, 0>::run(p, D, Mg, g);
     float *q = QV + bm * ((int64_t)n * 2 * D);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int c = 128 * g + 32 * a + ti, rho = 32 * b + tj;
+            const int c = 32 * (2 * a + g) + ti, rho = 32 * b + tj;
             if (c < D && rho < D) {
                 q[(int64_t)c * 2 * D + rho] = p[a][b].x;
                 q[(int64_t)c * 2 * D + D + rho] = -p[a][b].y;
