@@ -26,8 +26,12 @@ __device__ __forceinline__ float row32_sum(float x) {   // all-reduce over the 3
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, false));
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xF, 0xF, false));
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xF, 0xF, false));
-    x += __shfl_xor(x, 16, 64);
-    return x;
+    // every lane of a 16-lane row now holds its row's sum; add the partner row (0 <-> 1, 2 <-> 3) with
+    // v_permlane16_swap (gfx950: odd rows of the first operand <-> even rows of the second) instead of a
+    // ds_bpermute round trip through the LDS pipeline:  (a, b) = (x, x) -> a = [x0 x0 x2 x2], b = [x1 x1 x3 x3]
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
 }
 
 typedef float v2 __attribute__((ext_vector_type(2)));   // packed complex arithmetic, see tridiag_reg.hip
@@ -42,6 +46,23 @@ __device__ __forceinline__ v2 b_cmac(v2 acc, v2 m, v2 v, v2 vj) {   // acc + m v
 __device__ __forceinline__ v2 b_cmacc(v2 acc, v2 a, v2 aj, v2 b) {   // acc + a conj(b), aj = rotc(a)
     acc = __builtin_elementwise_fma(b.xx, a, acc);
     return __builtin_elementwise_fma(b.yy, aj, acc);
+}
+
+// operand-select forms (see tridiag_reg.hip): complex products straight from (re, im) pairs, no rotated copies.
+// Their results are invisible to the compiler's hazard recogniser: never feed one directly into a DPP read.
+__device__ __forceinline__ v2 b_cmac_sel(v2 acc, v2 m, v2 v) {   // acc + m v
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "+v"(acc)
+        : "v"(m), "v"(v));
+    return acc;
+}
+__device__ __forceinline__ v2 b_cmsubc_sel(v2 acc, v2 a, v2 b) {   // acc - a conj(b)
+    asm("v_pk_fma_f32 %0, %2, %1, %0 op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,1,0]"
+        : "+v"(acc)
+        : "v"(a), "v"(b));
+    return acc;
 }
 
 template <int NA>
@@ -272,33 +293,61 @@ __global__ __launch_bounds__(TB_THREADS) void tridiag_big_kernel(int D, float2 *
 
 // P = Q^H, the 32-row blocks {g, g + 2, g + 4, g + 6} handled by workgroup g (interleaved: the work per row grows
 // with the row index):  P <- P (I - conj(tau_u) v_u v_u^H), u = D-1 .. 0.
+// Two reflectors per pass (u, then u - 1):  P (I - c1 v1 v1^H)(I - c2 v2 v2^H) with c = conj(tau):
+//   y1 = P v1, y2 = P v2 in ONE sweep over the registers, P' v2 = y2 - c1 y1 (v1^H v2), then one rank-2 update.
+// Same flops as two single steps, half the serialized reduce -> broadcast -> update round trips.
 template <int NB, int B0>
-__device__ __forceinline__ void ub_step(float2 (&p)[4][NB], int u, int D, const float2 *__restrict__ Mg, int g) {
+__device__ __forceinline__ void ub_step2(float2 (&p)[4][NB], int u, int D, const float2 *__restrict__ Mg, int g) {
     const int tj = threadIdx.x & 31;
-    const float2 tau = Mg[(int64_t)D * D + u];
-    if (tau.x == 0.f && tau.y == 0.f) return;
-    v2 vc[NB], vj[NB];
+    // (a reflector with tau = 0 -- H = I -- needs no special case: its t below is zero.)  The last pass of a block
+    // with an odd number of reflectors has no second one: tau2 = 0.
+    const bool has2 = u - 1 >= 32 * B0;
+    const int u2 = has2 ? u - 1 : u;
+    const float2 tau1 = Mg[(int64_t)D * D + u];
+    const float2 tau2 = has2 ? Mg[(int64_t)D * D + u2] : make_float2(0.f, 0.f);
+    if (tau1.x == 0.f && tau1.y == 0.f && tau2.x == 0.f && tau2.y == 0.f) return;   // uniform
+    v2 va[NB], vb[NB];
 #pragma unroll
     for (int b = B0; b < NB; ++b) {
         const int j = 32 * b + tj;
-        vc[b] = (j < D) ? b_tov2(Mg[(int64_t)u * D + j]) : v2{0.f, 0.f};
-        vj[b] = b_rot(vc[b]);
+        va[b] = (j < D) ? b_tov2(Mg[(int64_t)u * D + j]) : v2{0.f, 0.f};
+        vb[b] = (j < D) ? b_tov2(Mg[(int64_t)u2 * D + j]) : v2{0.f, 0.f};
     }
-    const float2 ctau = make_float2(tau.x, -tau.y);
+    // s12 = v1^H v2 (every lane of a 32-lane row ends up with the full sum)
+    v2 s12 = {0.f, 0.f};
+#pragma unroll
+    for (int b = B0; b < NB; ++b) s12 = b_cmacc(s12, vb[b], b_rotc(vb[b]), va[b]);
+    s12.x = row32_sum(s12.x);
+    s12.y = row32_sum(s12.y);
+    const v2 c1 = v2{tau1.x, -tau1.y}, c2 = v2{tau2.x, -tau2.y};
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         // row r of P is still e_r while u > r (v_u vanishes above its unit entry): row blocks above the
         // reflector's block have nothing to do (uniform per workgroup)
         if (2 * a + g < B0) continue;
-        v2 y = {0.f, 0.f};
+        v2 y1 = {0.f, 0.f}, y2 = {0.f, 0.f};
 #pragma unroll
-        for (int b = B0; b < NB; ++b) y = b_cmac(y, b_tov2(p[a][b]), vc[b], vj[b]);
-        y.x = row32_sum(y.x);
-        y.y = row32_sum(y.y);
-        const float2 ty = cmul(ctau, b_tof2(y));
-        const v2 nty = v2{-ty.x, -ty.y}, ntyj = b_rotc(nty);
+        for (int b = B0; b < NB - 1; ++b) {
+            y1 = b_cmac_sel(y1, b_tov2(p[a][b]), va[b]);
+            y2 = b_cmac_sel(y2, b_tov2(p[a][b]), vb[b]);
+        }
+        // last term by the compiler: the DPP reduction reads y1 / y2 next
+        y1 = b_cmac(y1, b_tov2(p[a][NB - 1]), va[NB - 1], b_rot(va[NB - 1]));
+        y2 = b_cmac(y2, b_tov2(p[a][NB - 1]), vb[NB - 1], b_rot(vb[NB - 1]));
+        y1.x = row32_sum(y1.x);
+        y1.y = row32_sum(y1.y);
+        y2.x = row32_sum(y2.x);
+        y2.y = row32_sum(y2.y);
+        const v2 t1 = b_tov2(cmul(b_tof2(c1), b_tof2(y1)));
+        const float2 cor = cmul(b_tof2(t1), b_tof2(s12));
+        const v2 t2 = b_tov2(cmul(b_tof2(c2), make_float2(y2.x - cor.x, y2.y - cor.y)));
 #pragma unroll
-        for (int b = B0; b < NB; ++b) p[a][b] = b_tof2(b_cmacc(b_tov2(p[a][b]), nty, ntyj, vc[b]));
+        for (int b = B0; b < NB; ++b) {
+            v2 x = b_tov2(p[a][b]);
+            x = b_cmsubc_sel(x, t1, va[b]);
+            x = b_cmsubc_sel(x, t2, vb[b]);
+            p[a][b] = b_tof2(x);
+        }
     }
 }
 
@@ -307,7 +356,7 @@ struct UbPhases {
     static __device__ __forceinline__ void run(float2 (&p)[4][NB], int D, const float2 *Mg, int g) {
         if constexpr (B0 + 1 < NB) UbPhases<NB, B0 + 1>::run(p, D, Mg, g);
         const int hi = min(32 * (B0 + 1), D);
-        for (int u = hi - 1; u >= 32 * B0; --u) ub_step<NB, B0>(p, u, D, Mg, g);
+        for (int u = hi - 1; u >= 32 * B0; u -= 2) ub_step2<NB, B0>(p, u, D, Mg, g);
     }
 };
 
