@@ -33,6 +33,14 @@ __device__ __forceinline__ float row32_sum(float x) {   // all-reduce over the 3
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
     return a + b;
 }
+// x + (x of the lane 32 away): v_permlane32_swap exchanges the upper half of the first operand with the lower
+// half of the second
+__device__ __forceinline__ float half_pair_sum(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float wave_sum_fast(float x) { return half_pair_sum(row32_sum(x)); }   // all 64 lanes
 
 typedef float v2 __attribute__((ext_vector_type(2)));   // packed complex arithmetic, see tridiag_reg.hip
 __device__ __forceinline__ v2 b_tov2(float2 a) { return v2{a.x, a.y}; }
@@ -127,7 +135,7 @@ __device__ __forceinline__ void tb_step(float2 (&m)[tb_nslot(NA)], float2 *__res
         const float2 x = col[i];
         pn += x.x * x.x + x.y * x.y;
     }
-    const float xn2 = wave_sum(pn);
+    const float xn2 = wave_sum_fast(pn);
     const float2 alpha = sh.head[par];
     float beta, tr, tim, sr, si;
     householder_c(alpha.x, alpha.y, xn2, beta, tr, tim, sr, si);
@@ -178,8 +186,8 @@ __device__ __forceinline__ void tb_step(float2 (&m)[tb_nslot(NA)], float2 *__res
             float2 t = make_float2(0.f, 0.f);
 #pragma unroll
             for (int a = b + 1; a < NA; ++a) t = cmacc(t, TB_GET(a, b), vr[a]);   // conj(M_ij) v_i -> row j
-            t.x += __shfl_xor(t.x, 32, 64);
-            t.y += __shfl_xor(t.y, 32, 64);
+            t.x = half_pair_sum(t.x);
+            t.y = half_pair_sum(t.y);
             if (lane < 32) sh.cpart[wave][32 * b + tj] = t;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -201,8 +209,8 @@ __device__ __forceinline__ void tb_step(float2 (&m)[tb_nslot(NA)], float2 *__res
             sh.pfull[tid] = p;
             dotp = cmacc(dotp, p, vat(tid));
         }
-        dotp.x = wave_sum(dotp.x);
-        dotp.y = wave_sum(dotp.y);
+        dotp.x = wave_sum_fast(dotp.x);
+        dotp.y = wave_sum_fast(dotp.y);
         if (lane == 0) sh.dotbuf[wave] = dotp;
     }
     __syncthreads();   // (C)
