@@ -159,7 +159,8 @@ static bool fuse_back(int D, const Ws &ws) {
 }
 
 // The first G-layer (Z = 0) sees a plain arrowhead matrix: arrow.hip solves it directly in O(n^2)
-// (D <= 128).  ADMMNET_ARROW=0 sends it down the dense path like every other layer.
+// (fused with the rebuild for D <= 128, through the global eigenvector image above).  ADMMNET_ARROW=0 sends it
+// down the dense path like every other layer.
 static bool use_arrow(int D) {
     static const bool on = !(getenv("ADMMNET_ARROW") && atoi(getenv("ADMMNET_ARROW")) == 0);
     return on && arrow_rebuild_supported(D);
@@ -373,7 +374,7 @@ int admmnet_layer_front(const admmnet_cfg *cfg, const float *W, int32_t k, const
         float2 *Gk = ws.G + b0 * n * n;
         if (k == 0 && use_arrow(D)) {   // Z = 0: arrowhead, no matrix is ever formed
             if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, ws, false, st, true))) return rc;
-            if ((rc = launch_arrow_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, status, st, lean))) return rc;
+            if ((rc = launch_arrow_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, status, ws, st, lean))) return rc;
             continue;
         }
         if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, ws, false, st, false, lean))) return rc;
@@ -471,7 +472,7 @@ int admmnet_glayer_f32(const admmnet_cfg *cfg, const float *lw, const void *phi,
         if (!Zc && use_arrow(D)) {
             if ((rc = launch_arrow_rebuild(D, nb, lw, ph, h + b0 * D, (float2 *)G_out + b0 * n * n,
                                            rn_out ? rn_out + b0 : rn_tmp + b0, w_out ? w_out + b0 * n : nullptr,
-                                           status, st)))
+                                           status, ws, st)))
                 return rc;
             continue;
         }

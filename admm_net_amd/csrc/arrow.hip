@@ -35,10 +35,13 @@ __host__ __device__ inline size_t ar_lds_bytes(const BrGeom &g) {
     return sizeof(float) * (g.vt_floats() + g.small_floats() + 12 * NP) + sizeof(int) * 5 * NP + sizeof(DcRot) * NP;
 }
 
+// BIG (128 < D <= 256): the eigenvector image does not fit the LDS; it is built in the global VT buffer of the
+// dense path (rows c, planes at 0 / D, pitch 2 D) together with w and w0, and rebuild.hip's kernel consumes it.
+template <bool BIG>
 __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
     int D, const float *__restrict__ lw, const float2 *__restrict__ phi, const float *__restrict__ h,
     float2 *__restrict__ G, float *__restrict__ rn, float *__restrict__ w_out, int32_t *__restrict__ status,
-    unsigned long long *__restrict__ ptime, int lower_only) {
+    unsigned long long *__restrict__ ptime, int lower_only, float *VTg, float *__restrict__ w0g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ ArShared sh;
     // developer phase timer (ADMMNET_AR_TIMING=1): cycles of thread 0 between marks
@@ -51,13 +54,14 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
         }
     };
     const BrGeom g(D);
-    const int n = g.n, Dp = g.Dp, VP = g.VP;
+    const int n = g.n;
+    const int Dp = BIG ? D : g.Dp, VP = BIG ? 2 * D : g.VP;   // plane width / row pitch of the eigenvector image
     const int NP = (int)ar_np(D);
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
     const float alpha = lw[S_CORNER_G];   // corner of C = 1 / (lambda^2 + eps), admm_net.py:271
-    float *VTl = reinterpret_cast<float *>(smem);
-    float *fs = VTl + g.vt_floats();
+    float *VTl = BIG ? VTg + b * ((int64_t)n * 2 * D) : reinterpret_cast<float *>(smem);
+    float *fs = reinterpret_cast<float *>(smem) + (BIG ? 0 : g.vt_floats());
     float *w0f = fs + ((n + 4) & ~3);
     float *z0s = w0f + ((n + 4) & ~3);
     float *rowb = z0s + ((n + 4) & ~3);
@@ -226,6 +230,7 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
             w0f[c] = xa * f;
             z0s[c] = xa;
             if (w_out) w_out[b * n + c] = lam;
+            if (BIG) w0g[b * n + c] = xa;
         }
         if (tid == 0) {
             fs[n] = 0.f;
@@ -291,22 +296,35 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
     __syncthreads();
     mark(3);
     (void)status;
-    rebuild_from_lds(g, b, lw, VTl, fs, w0f, z0s, rowb, redb, phi, h, G, rn, [&](int id) { mark(id); }, lower_only);
+    if constexpr (BIG) return;
+    else rebuild_from_lds(g, b, lw, VTl, fs, w0f, z0s, rowb, redb, phi, h, G, rn, [&](int id) { mark(id); }, lower_only);
 }
 
-bool arrow_rebuild_supported(int D) { return D >= 1 && D <= 128; }
+bool arrow_rebuild_supported(int D) { return D >= 1 && D <= 256; }
 
 int launch_arrow_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G, float *rn,
-                         float *w_out, int32_t *status, hipStream_t st, bool lower_only) {
-    ProfScope _prof(KC_REBUILD, st);
+                         float *w_out, int32_t *status, const Ws &ws, hipStream_t st, bool lower_only) {
     if (nb <= 0) return ADMMNET_OK;
     if (!arrow_rebuild_supported(D)) {
         set_error("arrow_rebuild: D=%d unsupported", D);
         return ADMMNET_E_ARG;
     }
     const BrGeom g(D);
+    if (D > 128) {   // eigenvectors to the global image, then the dense path's rebuild kernel
+        {
+            ProfScope _prof(KC_REBUILD, st);
+            const size_t lds = ar_lds_bytes(g) - sizeof(float) * g.vt_floats();
+            ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(arrow_rebuild_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(arrow_rebuild_kernel<true>, dim3((unsigned)nb), dim3(AR_THREADS), lds, st, D, lw, phi, h,
+                               G, rn, ws.w, status, (unsigned long long *)nullptr, lower_only ? 1 : 0, ws.VT, ws.w0);
+            ADMM_HIP(hipGetLastError());
+        }
+        return launch_rebuild(D, nb, lw, phi, h, G, rn, w_out, ws, st, lower_only);
+    }
+    ProfScope _prof(KC_REBUILD, st);
     const size_t lds = ar_lds_bytes(g);
-    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(arrow_rebuild_kernel),
+    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(arrow_rebuild_kernel<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const bool timing = getenv("ADMMNET_AR_TIMING") != nullptr;   // developer aid, never on by default
     unsigned long long *ptime = nullptr;
@@ -314,8 +332,8 @@ int launch_arrow_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, 
         ADMM_HIP(hipMalloc(&ptime, 16 * sizeof(unsigned long long)));
         ADMM_HIP(hipMemsetAsync(ptime, 0, 16 * sizeof(unsigned long long), st));
     }
-    hipLaunchKernelGGL(arrow_rebuild_kernel, dim3((unsigned)nb), dim3(AR_THREADS), lds, st, D, lw, phi, h, G, rn,
-                       w_out, status, ptime, lower_only ? 1 : 0);
+    hipLaunchKernelGGL(arrow_rebuild_kernel<false>, dim3((unsigned)nb), dim3(AR_THREADS), lds, st, D, lw, phi, h, G, rn,
+                       w_out, status, ptime, lower_only ? 1 : 0, (float *)nullptr, (float *)nullptr);
     ADMM_HIP(hipGetLastError());
     if (timing) {
         unsigned long long hb[16];

@@ -137,7 +137,7 @@ int launch_peaks(const float2 *phi, int64_t B, int xbase, int ybase, const doubl
                  double *peaks, int32_t *counts, hipStream_t st);                          // peaks.hip
 bool arrow_rebuild_supported(int D);                                                       // arrow.hip
 int launch_arrow_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G, float *rn,
-                         float *w_out, int32_t *status, hipStream_t st, bool lower_only = false);   // arrow.hip
+                         float *w_out, int32_t *status, const Ws &ws, hipStream_t st, bool lower_only = false);   // arrow.hip
 bool back_rebuild_supported(int D);                                                        // backrebuild.hip
 int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G,
                         float *rn, float *w_out, const Ws &ws, hipStream_t st,
