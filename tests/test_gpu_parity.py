@@ -98,10 +98,13 @@ def test_glayer_block_vs_oracle(dev):
         assert rel(rn.cpu().numpy(), t["rn"].numpy()) < 1e-5
 
 
-def test_glayer_first_layer_arrowhead_edge_cases(dev):
-    """Layer 0 (Z = 0) runs the direct arrowhead eigensolver (arrow.hip): repeated h (rotation deflation),
-    zero phi entries (trivial deflation), all-equal h, strong coupling -- against the oracle's G-layer in f64."""
-    z, m, sd, (Nb, Nd, K, B, L, head, _) = load_case(os.path.join(ROOT, "tests/golden/phiest_8x16_K3_perturbed.npz"))
+@pytest.mark.parametrize("fixture", ["phiest_8x16_K3_perturbed", "phiest_16x16_K3_perturbed"],
+                         ids=["fused_D128", "global_image_D256"])
+def test_glayer_first_layer_arrowhead_edge_cases(dev, fixture):
+    """Layer 0 (Z = 0) runs the direct arrowhead eigensolver (arrow.hip; D <= 128 fused with the rebuild, larger D
+    through the global eigenvector image): repeated h (rotation deflation), zero phi entries (trivial deflation),
+    all-equal h, strong coupling -- against the oracle's G-layer in f64."""
+    z, m, sd, (Nb, Nd, K, B, L, head, _) = load_case(os.path.join(ROOT, f"tests/golden/{fixture}.npz"))
     D = Nb * Nd
     rng = np.random.default_rng(17)
     phis, hs = [], []
