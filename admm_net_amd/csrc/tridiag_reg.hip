@@ -305,8 +305,14 @@ __device__ __forceinline__ void q_load(float2 (&vn)[NA], int u, int D, const flo
     for (int b = B0; b < NA; ++b) {
         if constexpr (FULL) {
             vn[b] = row[16 * b];
+        } else if (b < NA - 1) {
+            vn[b] = row[16 * b];   // 16 (NA - 1) < D: only the last block has padding columns
         } else {
-            vn[b] = (16 * b + tj < D && u >= 0) ? row[16 * b] : make_float2(0.f, 0.f);
+            // unconditional load from a clamped address, value selected afterwards: a load inside a branch waits
+            // for the one before it, and the step then pays one memory round trip per block
+            const int j = 16 * b + tj;
+            const float2 x = row[min(j, D - 1) - tj];
+            vn[b] = (j < D) ? x : make_float2(0.f, 0.f);
         }
     }
 }
@@ -460,7 +466,8 @@ __global__ __launch_bounds__(TR_THREADS, 2) void tridiag_reg_kernel(int D, float
 #pragma unroll
             for (int b = 0; b < NA; ++b) {
                 const int i = 16 * a + ti, j = 16 * b + tj;
-                m[a][b] = (i < D && j < D) ? Mg[(int64_t)i * D + j] : make_float2(0.f, 0.f);
+                const float2 x = Mg[(int64_t)min(i, D - 1) * D + min(j, D - 1)];   // clamped, unconditional (see q_load)
+                m[a][b] = (i < D && j < D) ? x : make_float2(0.f, 0.f);
             }
         corner = ag[D].x;
         __syncthreads();   // all loads done before Mg rows are overwritten with reflectors
