@@ -23,14 +23,15 @@ namespace admmnet {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int DC_THREADS = 256;
-constexpr int DC_LS = 8;          // leaf size (the last leaf absorbs the remainder)
+constexpr int DC_LS = 8;          // nominal leaf size (dc_leaf_start in dc_core.h spreads the remainder)
 constexpr int DC_MAXLEAF = 33;    // n <= 8 * 33 + 7
-constexpr int DC_MAXLS = 2 * DC_LS;
-constexpr int DC_LDZ = DC_LS + 1;          // row pitch of a leaf's Z (odd: the team's row-per-lane accesses spread over banks)
-constexpr int DC_LDZ_LAST = DC_MAXLS + 1;  // the last leaf holds up to 2 * DC_LS - 1 rows
+constexpr int DC_MAXLS = 2 * DC_LS;   // a single leaf (n < 16) has up to 15 rows
 
-__host__ __device__ constexpr size_t dc_leafz_floats(int nleaf) {
-    return (size_t)(nleaf - 1) * DC_LS * DC_LDZ + (size_t)DC_MAXLS * DC_LDZ_LAST;
+// leaf scratch: Z of every leaf as [maxrows][maxrows | 1] (odd pitch: the team's row-per-lane accesses spread
+// over the banks)
+__host__ __device__ inline size_t dc_leafz_floats(int n) {
+    const int nleaf = dc_leaf_count(n), mr = dc_leaf_maxrows(n, nleaf);
+    return (size_t)nleaf * mr * (mr | 1);
 }
 
 struct DcShared {
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
     int *rnk = org + NP;
     int *cidx = rnk + NP;                                      // source column (block-local) of merged position p
     DcRot *rot = reinterpret_cast<DcRot *>(cidx + NP);         // [NP]
-    float *leafZ = reinterpret_cast<float *>(rot + NP);         // [nleaf - 1][DC_LS * DC_LDZ] + [DC_MAXLS * DC_LDZ_LAST]
-    float *leafD = leafZ + dc_leafz_floats(max(1, n / DC_LS));   // [nleaf][2 * DC_MAXLS]
+    float *leafZ = reinterpret_cast<float *>(rot + NP);         // [nleaf][maxrows][maxrows | 1]
+    float *leafD = leafZ + dc_leafz_floats(n);                  // [nleaf][2 * DC_MAXLS]
 
     float *WA = Wbuf + bm * (int64_t)3 * n * n;
     float *WB = WA + (int64_t)n * n;
@@ -91,9 +92,9 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
     const float *dg = dT + bm * n, *eg = eT + bm * n;
 
     // ---- leaves
-    const int nleaf = max(1, n / DC_LS);
+    const int nleaf = dc_leaf_count(n);
     if (tid == 0) {
-        for (int b = 0; b < nleaf; ++b) sh.bnd[0][b] = b * DC_LS;
+        for (int b = 0; b < nleaf; ++b) sh.bnd[0][b] = dc_leaf_start(n, nleaf, b);
         sh.bnd[0][nleaf] = n;
         sh.fail = 0;
     }
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
     mark(0);
     // tear: d[k-1] -= |e[k-1]|, d[k] -= |e[k-1]| at every leaf boundary k
     for (int b = 1 + tid; b < nleaf; b += DC_THREADS) {
-        const int k = b * DC_LS;
+        const int k = dc_leaf_start(n, nleaf, b);
         const float r = fabsf(e0[k - 1]);
         lam[k - 1] -= r;   // each boundary touches its own two entries (leaves have >= 8 rows)
         lam[k] -= r;
@@ -122,8 +123,8 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         if (leaf < nleaf) {
             const int a = sh.bnd[0][leaf], s = sh.bnd[0][leaf + 1] - a;
             float *dd = leafD + (size_t)leaf * 2 * DC_MAXLS, *ee = dd + DC_MAXLS;
-            float *Z = leafZ + (size_t)leaf * DC_LS * DC_LDZ;
-            const int ldz = (leaf == nleaf - 1) ? DC_LDZ_LAST : DC_LDZ;
+            const int mr = dc_leaf_maxrows(n, nleaf), ldz = mr | 1;
+            float *Z = leafZ + (size_t)leaf * mr * ldz;
             for (int i = 0; i < s; ++i) {   // identical values from every lane of the team
                 dd[i] = lam[a + i];
                 ee[i] = (i < s - 1) ? e0[a + i] : 0.f;
@@ -486,8 +487,8 @@ __global__ __launch_bounds__(256) void vgemm_kernel(int D, const float *__restri
 
 size_t dc_lds_bytes(int n) {
     const int NP = (n + 3) & ~3;
-    const size_t nleaf = (size_t)(n / DC_LS > 0 ? n / DC_LS : 1);
-    size_t leaf = dc_leafz_floats((int)nleaf) + nleaf * 2 * DC_MAXLS;
+    const size_t nleaf = (size_t)dc_leaf_count(n);
+    size_t leaf = dc_leafz_floats(n) + nleaf * 2 * DC_MAXLS;
     if (leaf < 32 * 33) leaf = 32 * 33;   // the final transpose reuses the leaf scratch as a tile
     return sizeof(float) * 11 * NP + sizeof(int) * 5 * NP + sizeof(DcRot) * NP + sizeof(float) * leaf;
 }
@@ -495,7 +496,7 @@ size_t dc_lds_bytes(int n) {
 // float offset (inside one matrix' 3 n^2 block) of the ping-pong buffer that holds the final WT[j][i]: the
 // merge loop swaps buffers once per level
 int64_t dc_final_offset(int n) {
-    int nblk = n / DC_LS > 0 ? n / DC_LS : 1, levels = 0;
+    int nblk = dc_leaf_count(n), levels = 0;
     while (nblk > 1) {
         nblk = (nblk >> 1) + (nblk & 1);
         ++levels;

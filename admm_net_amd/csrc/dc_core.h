@@ -27,6 +27,15 @@ HD float fdiv_fast(float a, float b) {
 #endif
 }
 
+// Leaf partition of an n x n tridiagonal: nleaf = max(1, n / 8) leaves of n / nleaf rows, the last n % nleaf of
+// them one row longer (n = 129 -> 15 x 8 + 9, n = 101 -> 7 x 8 + 5 x 9: no leaf much slower than the others).
+HD int dc_leaf_count(int n) { return n / 8 > 0 ? n / 8 : 1; }
+HD int dc_leaf_start(int n, int nleaf, int b) {
+    const int base = n / nleaf, big0 = nleaf - n % nleaf;   // leaves >= big0 have base + 1 rows
+    return b * base + (b > big0 ? b - big0 : 0);
+}
+HD int dc_leaf_maxrows(int n, int nleaf) { return n / nleaf + (n % nleaf ? 1 : 0); }
+
 // ---------------------------------------------------------------------------------------------
 // Leaf solver: implicit QL with eigenvectors on a tiny tridiagonal (s <= 16).
 // d[s], e[s] (e[i] couples i, i+1; e[s-1] ignored); Z row-major [s][ldz] receives the eigenvectors

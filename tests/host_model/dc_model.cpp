@@ -13,7 +13,7 @@ using namespace admmnet;
 
 namespace {
 
-constexpr int LS = 8;   // leaf size (last leaf absorbs the remainder, < 2*LS)
+constexpr int LS = 8;   // nominal leaf size (dc_leaf_start spreads the remainder; a single leaf has < 2*LS rows)
 
 struct Ctx {
     int n;
@@ -128,9 +128,9 @@ int dc_solve(int n, const float *d_in, const float *e_in, float *lam_out, float 
     cx.WB.assign((size_t)n * n, 0.f);
     cx.e0.assign(e_in, e_in + n);
     std::vector<float> d(d_in, d_in + n);
-    const int nblk = std::max(1, n / LS);
+    const int nblk = dc_leaf_count(n);
     std::vector<int> bnd(nblk + 1);
-    for (int b = 0; b < nblk; ++b) bnd[b] = b * LS;
+    for (int b = 0; b < nblk; ++b) bnd[b] = dc_leaf_start(n, nblk, b);
     bnd[nblk] = n;
     for (int b = 1; b < nblk; ++b) {
         const int k = bnd[b];
