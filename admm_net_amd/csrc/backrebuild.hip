@@ -253,6 +253,7 @@ int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, c
     auto kern = nct == 1   ? (v4 ? back_rebuild_kernel<1, 0, true> : back_rebuild_kernel<1, 0, false>)
                 : nct == 2 ? (v4 ? back_rebuild_kernel<2, 0, true> : back_rebuild_kernel<2, 0, false>)
                 : nct == 3 ? (v4 ? back_rebuild_kernel<3, 0, true> : back_rebuild_kernel<3, 0, false>)
+                : D == 100 ? back_rebuild_kernel<4, 7, true>   // the reference's default 10 x 10 grid: unrolled slab loop too
                 : nct == 4 ? (v4 ? back_rebuild_kernel<4, 0, true> : back_rebuild_kernel<4, 0, false>)
                 : D == 128 ? back_rebuild_kernel<5, 8, true>
                            : (v4 ? back_rebuild_kernel<5, 0, true> : back_rebuild_kernel<5, 0, false>);
