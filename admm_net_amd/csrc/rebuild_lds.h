@@ -137,11 +137,19 @@ __device__ __forceinline__ void rebuild_from_lds(const BrGeom &g, int64_t b, con
 
     mark(4);
     // ---------------- arrow row (perm row 0 = original row D): G'[0][j] = sum_c w0_c f_c conj(V[j][c])
-    for (int rp = tid; rp < 2 * Dp; rp += BR_THREADS) {
-        float a = 0.f;
+    //   When the tiles do not divide evenly over the four waves (10 tiles at NT = 4: 3, 3, 2, 2) the waves with
+    //   one tile fewer take this row, while the others are still in their last tile.
+    {
+        const int heavy = ntiles & 3;                                   // waves [0, heavy) had one tile more
+        const int first = heavy ? heavy : 0, nl = BR_THREADS / 64 - first;
+        if (wave >= first) {
+            for (int rp = tid - 64 * first; rp < 2 * Dp; rp += 64 * nl) {
+                float a = 0.f;
 #pragma unroll 8
-        for (int c = 0; c < n; ++c) a = fmaf(w0f[c], VTl[c * VP + rp], a);
-        rowb[rp] = a;
+                for (int c = 0; c < n; ++c) a = fmaf(w0f[c], VTl[c * VP + rp], a);
+                rowb[rp] = a;
+            }
+        }
     }
     __syncthreads();
     for (int o = tid; o < D; o += BR_THREADS) {
