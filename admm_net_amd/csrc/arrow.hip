@@ -23,7 +23,7 @@ namespace admmnet {
 constexpr int AR_THREADS = 256;
 
 struct ArShared {
-    int k, nrot;
+    int k, nrot, conf;
     int mx[2];
     float znorm;
 };
@@ -123,12 +123,23 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
         const float dmax = __int_as_float(sh.mx[0]), zmax = __int_as_float(sh.mx[1]);
         int trig = 0;
         for (int p = tid; p < D; p += AR_THREADS) trig |= deflate_triggers(p, 1.0f, dmax, zmax, ds, zs) ? 1 : 0;
-        if (__syncthreads_or(trig)) {
-            if (tid == 0) {
-                int k = 0, nr = 0;
-                deflate_scan_tol(D, 1.0f, dmax, zmax, ds, zs, dl, zl, src, rot, k, nr);
-                sh.k = k;
-                sh.nrot = nr;
+        if (__syncthreads_or(trig)) {   // team form of the scan (dc_core.h), later phases' arrays as scratch
+            const float tol = 8.0f * kEps32 * fmaxf(dmax, zmax);
+            float *dde = reinterpret_cast<float *>(kidx);
+            defl_par_flags(tid, AR_THREADS, D, 1.0f, tol, ds, zs, org, rnk, tau, zh);
+            if (tid == 0) sh.conf = 0;
+            __syncthreads();
+            defl_par_walk(tid, AR_THREADS, D, tol, ds, zs, org, rnk, tau, zh, vals, x0, dde, &sh.conf);
+            __syncthreads();
+            if (sh.conf) {   // a rotation chain grew into the next run of candidates: serial scan
+                if (tid == 0) {
+                    int k = 0, nr = 0;
+                    deflate_scan_tol(D, 1.0f, dmax, zmax, ds, zs, dl, zl, src, rot, k, nr);
+                    sh.k = k;
+                    sh.nrot = nr;
+                }
+            } else {
+                defl_par_emit(tid, AR_THREADS, D, ds, org, rnk, tau, zh, vals, x0, dde, dl, zl, src, rot, &sh.k, &sh.nrot);
             }
         } else {
             for (int p = tid; p < D; p += AR_THREADS) {

@@ -38,6 +38,7 @@ struct DcShared {
     int bnd[2][DC_MAXLEAF + 2];
     int kk[DC_MAXLEAF];      // non-deflated count per merge
     int nrot[DC_MAXLEAF];
+    int conf[DC_MAXLEAF];    // team scan: a rotation chain reached the next run -> serial scan for this merge
     int mx[DC_MAXLEAF][2];   // max |d|, max |z| of a merge as float bit patterns (non-negative: integer order)
     int fail;
 };
@@ -199,18 +200,41 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         }
         __syncthreads();
         mark(2);
-        // P2: deflation scan (one thread per merge)
-        if (act && tl == 0) {
-            int k = 0, nr = 0;
-            deflate_scan_tol(nn, rho, __int_as_float(sh.mx[team][0]), __int_as_float(sh.mx[team][1]), ds + a, zs + a,
-                             dl + a, zl + a, src + a, rot + a, k, nr);
-            sh.kk[team] = k;
-            sh.nrot[team] = nr;
-            for (int p = k; p < nn; ++p) vals[a + p] = dl[a + p];
+        // P2: deflation scan, team form (defl_par_* in dc_core.h: flags, chain walkers, emission by counting; the
+        //     arrays of the later phases serve as scratch).  A chain that grows into the next run of candidates
+        //     is left to the serial scan.
+        {
+            const float dmx = act ? __int_as_float(sh.mx[team][0]) : 0.f, zmx = act ? __int_as_float(sh.mx[team][1]) : 0.f;
+            const float tol = 8.0f * kEps32 * fmaxf(dmx, zmx);
+            float *dde = reinterpret_cast<float *>(cidx);
+            if (act) {
+                defl_par_flags(tl, ts, nn, rho, tol, ds + a, zs + a, org + a, rnk + a, tau + a, zh + a);
+                if (tl == 0) sh.conf[team] = 0;
+            }
+            __syncthreads();
+            if (act)
+                defl_par_walk(tl, ts, nn, tol, ds + a, zs + a, org + a, rnk + a, tau + a, zh + a, lamn + a, vals + a,
+                              dde + a, &sh.conf[team]);
+            __syncthreads();
+            if (act) {
+                if (sh.conf[team]) {
+                    if (tl == 0) {
+                        int k = 0, nr = 0;
+                        deflate_scan_tol(nn, rho, dmx, zmx, ds + a, zs + a, dl + a, zl + a, src + a, rot + a, k, nr);
+                        sh.kk[team] = k;
+                        sh.nrot[team] = nr;
+                    }
+                } else {
+                    defl_par_emit(tl, ts, nn, ds + a, org + a, rnk + a, tau + a, zh + a, lamn + a, vals + a, dde + a,
+                                  dl + a, zl + a, src + a, rot + a, &sh.kk[team], &sh.nrot[team]);
+                }
+            }
         }
         __syncthreads();
         mark(3);
         const int k = act ? sh.kk[team] : 0;
+        if (act)
+            for (int p = k + tl; p < nn; p += ts) vals[a + p] = dl[a + p];   // eigenvalues of the deflated poles
         if (ptime && act && tl == 0) {   // developer statistics: merge sizes, non-deflated counts, rotations per level
             atomicAdd(&ptime[64 + 4 * min(lvl, 5) + 0], (unsigned long long)nn);
             atomicAdd(&ptime[64 + 4 * min(lvl, 5) + 1], (unsigned long long)k);

@@ -253,6 +253,135 @@ HD void deflate_scan_tol(int nn, float rho, float dmax, float zmax, FA ds, FA zs
     nrot_out = nrot;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Team form of the scan: same outputs as deflate_scan_tol, bit for bit, in three phases separated by team
+// barriers.  The serial chain only carries state across a rotation (the survivor's d and z change), so:
+//   A  every position evaluates its own tests against its predecessor's ORIGINAL values -- exact wherever
+//      the predecessor does not come out of a rotation;
+//   B  one walker per run of consecutive rotation candidates replays the chain through that run (and on,
+//      while the modified values keep rotating); a chain that runs into the head of another run raises
+//      `conflict` and the caller falls back to the serial scan (rare);
+//   C  output positions by counting: k2 slots from the number of deflation events before a step, rotation
+//      slots from the rotations before it, non-deflated slots from (non-tiny positions) - (rotations).
+// Work arrays of length nn: pv (previous non-tiny position), flg (DF_* bits), dvf / zvf (values a position
+// carries forward), rc / rs (rotation at step j), dde (value of the pole deflated by that rotation).
+constexpr int DF_TINY = 1, DF_R0 = 2, DF_ROT = 4;
+
+template <class FA>
+HD bool defl_close(float tol, float dpj, float zpj, float dj, float zj, FA) {
+    const float q = zj * zj + zpj * zpj;
+    const float t = dj - dpj;
+    return (fabsf(t * zj * zpj) <= tol * q) && !(q < 1e-30f);
+}
+
+template <class FA, class IA>
+HD void defl_par_flags(int tl, int ts, int nn, float rho, float tol, FA ds, FA zs, IA pv, IA flg, FA dvf, FA zvf) {
+    for (int j = tl; j < nn; j += ts) {
+        const float dj = ds[j], zj = zs[j];
+        int f = (rho * fabsf(zj) <= tol) ? DF_TINY : 0;
+        int p = j - 1;
+        while (p >= 0 && rho * fabsf(zs[p]) <= tol) --p;   // previous non-tiny position (tiny entries are rare)
+        if (!f && p >= 0 && defl_close(tol, ds[p], zs[p], dj, zj, ds)) f |= DF_R0;
+        pv[j] = p;
+        flg[j] = f;
+        dvf[j] = dj;
+        zvf[j] = zj;
+    }
+}
+
+template <class FA, class IA>
+HD void defl_par_walk(int tl, int ts, int nn, float tol, FA ds, FA zs, IA pv, IA flg, FA dvf, FA zvf, FA rc, FA rs,
+                      FA dde, int *conflict) {
+    for (int j0 = tl; j0 < nn; j0 += ts) {
+        if (!(flg[j0] & DF_R0) || (flg[pv[j0]] & DF_R0)) continue;   // heads of runs only
+        int pj = pv[j0], cur = j0;
+        float dpj = ds[pj], zpj = zs[pj];
+        for (;;) {
+            const float dj = ds[cur], zj = zs[cur];
+            const int fc = flg[cur];
+            const bool rotd = defl_close(tol, dpj, zpj, dj, zj, ds);
+            if (rotd) {
+                const float q = zj * zj + zpj * zpj;
+                const float itau = rsqrt_nr(q);
+                const float tau = q * itau;
+                const float c = zj * itau, s = -zpj * itau;
+                rc[cur] = c;
+                rs[cur] = s;
+                dde[cur] = dpj * c * c + dj * s * s;
+                dpj = dpj * s * s + dj * c * c;
+                zpj = tau;
+                dvf[cur] = dpj;
+                zvf[cur] = zpj;
+                flg[cur] = fc | DF_ROT;
+            } else {
+                dpj = dj;
+                zpj = zj;
+            }
+            int nx = cur + 1;
+            while (nx < nn && (flg[nx] & DF_TINY)) ++nx;
+            if (nx >= nn) break;
+            const bool r0c = fc & DF_R0, r0n = flg[nx] & DF_R0;
+            if (!rotd && !(r0c && r0n)) break;   // clean from here (a following run has its own walker)
+            if (rotd && !r0c && r0n) {           // the chain grew into the head of another run
+                *conflict = 1;
+                break;
+            }
+            pj = cur;
+            cur = nx;
+        }
+    }
+}
+
+template <class FA, class IA, class RA>
+HD void defl_par_emit(int tl, int ts, int nn, FA ds, IA pv, IA flg, FA dvf, FA zvf, FA rc, FA rs, FA dde, FA dl,
+                      FA zl, IA src, RA rot, int *k_out, int *nrot_out) {
+    for (int j = tl; j < nn; j += ts) {
+        int ntiny = 0, nrot = 0;   // tiny entries / rotations at steps before j
+#pragma unroll 4
+        for (int i = 0; i < j; ++i) {
+            const int f = flg[i];
+            ntiny += f & DF_TINY;
+            nrot += (f & DF_ROT) ? 1 : 0;
+        }
+        const int f = flg[j];
+        const int k2 = nn - 1 - (ntiny + nrot);   // the serial scan fills the deflated slots from the top, one per event
+        if (f & DF_TINY) {
+            dl[k2] = ds[j];
+            src[k2] = j;
+            continue;
+        }
+        if (f & DF_ROT) {
+            dl[k2] = dde[j];
+            src[k2] = pv[j];
+            DcRot r;
+            r.pa = pv[j];
+            r.pb = j;
+            r.c = rc[j];
+            r.s = rs[j];
+            rot[nrot] = r;
+        }
+        int nx = j + 1;
+        while (nx < nn && (flg[nx] & DF_TINY)) ++nx;
+        if (nx >= nn || !(flg[nx] & DF_ROT)) {   // position j survives: slot = non-tiny positions before - rotations up to j
+            const int idx = (j - ntiny) - (nrot + ((f & DF_ROT) ? 1 : 0));
+            dl[idx] = dvf[j];
+            zl[idx] = zvf[j];
+            src[idx] = j;
+        }
+    }
+    if (tl == 0) {
+        int ntiny = 0, nrot = 0;
+#pragma unroll 4
+        for (int i = 0; i < nn; ++i) {
+            const int f = flg[i];
+            ntiny += f & DF_TINY;
+            nrot += (f & DF_ROT) ? 1 : 0;
+        }
+        *k_out = (nn - ntiny) - nrot;
+        *nrot_out = nrot;
+    }
+}
+
 // Fast path of the scan: does ANY deflation trigger at sorted position p?  When no position says yes
 // the serial scan would keep every entry (its running pj is always p - 1), so the caller may skip it and
 // copy (ds, zs) -> (dl, zl), src = identity, k = nn, nrot = 0 in parallel.  Same tests, same tolerance.

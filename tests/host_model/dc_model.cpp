@@ -118,6 +118,48 @@ int merge(Ctx &cx, int a, int b, int c, const std::vector<float> &srcW, std::vec
 
 extern "C" {
 
+// Team form of the deflation scan (defl_par_* in dc_core.h), emulated with `ts` sequential "threads" per phase,
+// against the serial scan: returns 0 when every output is identical (bit for bit), 1 otherwise, 2 when the team
+// form reported a conflict (the device then falls back to the serial scan).  out[0..1] = k, nrot of the serial scan.
+int deflate_compare(int nn, float rho, const float *ds_in, const float *zs_in, int ts, int *out) {
+    std::vector<float> ds(ds_in, ds_in + nn), zs(zs_in, zs_in + nn);
+    float dmax = 0.f, zmax = 0.f;
+    for (int i = 0; i < nn; ++i) {
+        dmax = std::fmax(dmax, std::fabs(ds[i]));
+        zmax = std::fmax(zmax, std::fabs(zs[i]));
+    }
+    std::vector<float> dl(nn, -7.f), zl(nn, -7.f), dl2(nn, -7.f), zl2(nn, -7.f);
+    std::vector<int> src(nn, -7), src2(nn, -7);
+    std::vector<DcRot> rot(nn), rot2(nn);
+    int k = 0, nr = 0, k2 = 0, nr2 = 0;
+    deflate_scan_tol(nn, rho, dmax, zmax, ds.data(), zs.data(), dl.data(), zl.data(), src.data(), rot.data(), k, nr);
+    out[0] = k;
+    out[1] = nr;
+    const float tol = 8.0f * kEps32 * std::fmax(dmax, zmax);
+    std::vector<int> pv(nn), flg(nn);
+    std::vector<float> dvf(nn), zvf(nn), rc(nn), rs(nn), dde(nn);
+    int conflict = 0;
+    for (int tl = 0; tl < ts; ++tl)
+        defl_par_flags(tl, ts, nn, rho, tol, ds.data(), zs.data(), pv.data(), flg.data(), dvf.data(), zvf.data());
+    for (int tl = ts - 1; tl >= 0; --tl)   // (any order: walkers are independent)
+        defl_par_walk(tl, ts, nn, tol, ds.data(), zs.data(), pv.data(), flg.data(), dvf.data(), zvf.data(), rc.data(),
+                      rs.data(), dde.data(), &conflict);
+    if (conflict) return 2;
+    for (int tl = 0; tl < ts; ++tl)
+        defl_par_emit(tl, ts, nn, ds.data(), pv.data(), flg.data(), dvf.data(), zvf.data(), rc.data(), rs.data(),
+                      dde.data(), dl2.data(), zl2.data(), src2.data(), rot2.data(), &k2, &nr2);
+    if (k != k2 || nr != nr2) return 1;
+    for (int i = 0; i < nn; ++i) {
+        if (std::memcmp(&dl[i], &dl2[i], 4) || src[i] != src2[i]) return 1;
+        if (i < k && std::memcmp(&zl[i], &zl2[i], 4)) return 1;
+    }
+    for (int i = 0; i < nr; ++i)
+        if (rot[i].pa != rot2[i].pa || rot[i].pb != rot2[i].pb || std::memcmp(&rot[i].c, &rot2[i].c, 4) ||
+            std::memcmp(&rot[i].s, &rot2[i].s, 4))
+            return 1;
+    return 0;
+}
+
 // d[n], e[n] (e[i] couples i, i+1) -> lam[n] ascending, WT[n*n] with WT[j*n+i] = W[i][j].
 // stats[4]: deflated count, secular roots solved, secular iterations (sum, max).  Returns 0 or the leaf status.
 int dc_solve(int n, const float *d_in, const float *e_in, float *lam_out, float *WT_out, int *stats) {

@@ -331,6 +331,46 @@ def test_dc_model(dc_model, name):
     assert st[3] <= 25   # middle-way iteration: a handful of passes per root, bisection fallbacks are rare
 
 
+def test_team_deflation_scan_equals_serial_scan(dc_model):
+    """defl_par_* (dc_core.h), the team form of the D&C deflation scan, must reproduce the serial scan bit for bit:
+    random poles, clustered poles (rotation chains), tiny z entries, everything-deflates, and chains that grow
+    past their run; a reported conflict (2) is allowed -- the device then runs the serial scan -- but must be rare."""
+    rng = np.random.default_rng(123)
+    out = (ctypes.c_int * 2)()
+    conflicts = total = rotations = 0
+
+    def run(ds, zs, rho, ts):
+        nonlocal conflicts, total, rotations
+        ds = np.sort(ds.astype(np.float32)); zs = zs.astype(np.float32)
+        rc = dc_model.deflate_compare(len(ds), ctypes.c_float(rho), ds.ctypes.data_as(ctypes.c_void_p),
+                                      zs.ctypes.data_as(ctypes.c_void_p), ts, out)
+        assert rc in (0, 2), (rc, len(ds), ts)
+        total += 1
+        conflicts += rc == 2
+        rotations += out[1]
+
+    for trial in range(300):
+        nn = int(rng.integers(1, 260))
+        ts = int(rng.choice([1, 32, 64, 256]))
+        kind = trial % 6
+        ds = rng.standard_normal(nn)
+        zs = rng.standard_normal(nn)
+        zs /= max(np.linalg.norm(zs), 1e-30)
+        if kind == 1:     # clusters of nearly equal poles: rotation chains
+            ds = np.round(ds, 1) + 1e-8 * rng.standard_normal(nn)
+        elif kind == 2:   # many tiny z
+            zs[rng.random(nn) < 0.4] *= 1e-9
+        elif kind == 3:   # bench-like: poles within 1e-6 of each other in a +-0.006 band, O(0.1) couplings
+            ds = rng.uniform(-0.006, 0.006, nn); zs = 0.1 * np.abs(rng.standard_normal(nn))
+        elif kind == 4:   # everything equal
+            ds[:] = 0.37
+        elif kind == 5:   # negligible rank-one term
+            zs *= 1e-12
+        run(ds, zs, float(rng.choice([1.0, 2.0 * abs(rng.standard_normal()) + 1e-3])), ts)
+    assert rotations > 1000            # the cases do exercise the rotation path
+    assert conflicts <= total // 20    # and the fallback stays an exception
+
+
 # ---------------------------------------------------------------- host model of the arrowhead eigensolver (first G-layer)
 @pytest.fixture(scope="module")
 def arrow_model():
