@@ -54,14 +54,19 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
     const int tid = threadIdx.x;
     const int64_t bm = blockIdx.x;
     const int NP = (n + 3) & ~3;
-    // developer phase timer (ADMMNET_DC_TIMING=1): cycles of workgroup thread 0 between barriers
+    // developer phase timer (ADMMNET_DC_TIMING=1): cycles of workgroup thread 0 between barriers, accumulated in
+    // LDS and flushed once at the end (an atomic per mark would sit in front of the next barrier's vmcnt(0) and
+    // charge its own -- contended -- latency to every phase)
+    __shared__ unsigned int tacc[64], tstat[24];
+    if (ptime && tid < 64) tacc[tid] = 0;
+    if (ptime && tid < 24) tstat[tid] = 0;
     long long t_prev = ptime ? clock64() : 0;
     int lvl = 0;
     auto mark = [&](int id) {
         if (ptime && tid == 0) {
             const long long t_now = clock64();
-            atomicAdd(&ptime[id], (unsigned long long)(t_now - t_prev));
-            if (id >= 2 && id <= 8) atomicAdd(&ptime[16 + 8 * min(lvl, 5) + id - 2], (unsigned long long)(t_now - t_prev));
+            tacc[id] += (unsigned int)(t_now - t_prev);
+            if (id >= 2 && id <= 8) tacc[16 + 8 * min(lvl, 5) + id - 2] += (unsigned int)(t_now - t_prev);
             t_prev = t_now;
         }
     };
@@ -236,10 +241,10 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         if (act)
             for (int p = k + tl; p < nn; p += ts) vals[a + p] = dl[a + p];   // eigenvalues of the deflated poles
         if (ptime && act && tl == 0) {   // developer statistics: merge sizes, non-deflated counts, rotations per level
-            atomicAdd(&ptime[64 + 4 * min(lvl, 5) + 0], (unsigned long long)nn);
-            atomicAdd(&ptime[64 + 4 * min(lvl, 5) + 1], (unsigned long long)k);
-            atomicAdd(&ptime[64 + 4 * min(lvl, 5) + 2], (unsigned long long)sh.nrot[team]);
-            atomicAdd(&ptime[64 + 4 * min(lvl, 5) + 3], 1ull);
+            atomicAdd(&tstat[4 * min(lvl, 5) + 0], (unsigned int)nn);
+            atomicAdd(&tstat[4 * min(lvl, 5) + 1], (unsigned int)k);
+            atomicAdd(&tstat[4 * min(lvl, 5) + 2], (unsigned int)sh.nrot[team]);
+            atomicAdd(&tstat[4 * min(lvl, 5) + 3], 1u);
         }
         // P3: deflation rotations on the source columns (thread-private rows i) + secular roots
         if (act) {
@@ -464,6 +469,11 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         }
     }
     mark(9);
+    if (ptime) {
+        __syncthreads();
+        if (tid < 64 && tacc[tid]) atomicAdd(&ptime[tid], (unsigned long long)tacc[tid]);
+        if (tid < 24 && tstat[tid]) atomicAdd(&ptime[64 + tid], (unsigned long long)tstat[tid]);
+    }
     if (tid == 0) {
         logn[bm * 2 + 0] = 0;
         logn[bm * 2 + 1] = sh.fail ? 1 : 0;
