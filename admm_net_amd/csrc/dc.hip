@@ -67,6 +67,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
             const long long t_now = clock64();
             tacc[id] += (unsigned int)(t_now - t_prev);
             if (id >= 2 && id <= 8) tacc[16 + 8 * min(lvl, 5) + id - 2] += (unsigned int)(t_now - t_prev);
+            if (id == 11) tacc[16 + 8 * min(lvl, 5) + 7] += (unsigned int)(t_now - t_prev);   // GEMM of this level
             t_prev = t_now;
         }
     };
@@ -575,7 +576,7 @@ int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, 
                         (double)h[64 + 4 * l + 2] / h[64 + 4 * l + 3]);
         for (int l = 0; l < 6; ++l) {
             fprintf(stderr, "   level %d:", l);
-            for (int q = 0; q < 7; ++q) fprintf(stderr, " %8.0f", (double)h[16 + 8 * l + q] / (double)nb);
+            for (int q = 0; q < 8; ++q) fprintf(stderr, " %8.0f", (double)h[16 + 8 * l + q] / (double)nb);   // P1..P7, GEMM
             fprintf(stderr, "\n");
         }
     }
