@@ -203,6 +203,35 @@ def test_layer_api_and_sharded_single_rank(dev):
     assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("geom", [(8, 16, 4), (16, 16, 3)], ids=["8x16", "16x16"])
+def test_degenerate_inputs_match_oracle(dev, geom):
+    """Edge inputs of the data domain: an all-zero observation (phi = 0: the arrowhead layer deflates everything,
+    later layers see diagonal + corner matrices), a single non-zero sample, a batch of one, identical signals
+    (equal residual norms in the batch mean), a huge and a tiny overall scale."""
+    Nb, Nd, K = geom
+    torch.manual_seed(6)
+    m = A.PhiEstADMMNet(M=Nb, N=Nd, num_layers=K).eval()
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    y, b, s, _ = synth.make_batch(6, Nb, Nd, seed=9)
+    y[0] = 0
+    y[1] = 0
+    y[1, 5] = 1.0 + 0.5j
+    y[2] = y[3]
+    b[2] = b[3]
+    s[2] = s[3]
+    y[4] *= 1e3
+    y[5] *= 1e-4
+    for sl in (slice(0, 6), slice(0, 1)):
+        ty, tb, ts = (torch.from_numpy(v[sl]) for v in (y, b, s))
+        ref = R.forward(sd, ty, tb, ts, Nb, Nd, K, 3, dtype="f64").numpy()
+        got = m(ty.to(dev), tb.to(dev), ts.to(dev)).cpu().numpy()
+        assert np.isfinite(got).all()
+        # per signal: the scales differ by 1e7 across the batch
+        for i in range(got.shape[0]):
+            den = max(np.abs(ref[i]).max(), 1e-30)
+            assert np.abs(got[i] - ref[i]).max() <= 2e-4 * den + 1e-12, (i, np.abs(got[i] - ref[i]).max(), den)
+
+
 def test_fails_loudly_on_nonfinite_input(dev):
     m = A.PhiEstADMMNet(M=3, N=3, num_layers=3).eval()
     y, b, s, _ = synth.make_batch(2, 3, 3, seed=1)
