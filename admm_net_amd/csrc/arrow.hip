@@ -171,31 +171,39 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
         if (tid == 0) vals[0] = alpha;
     } else {
         const float znorm = sh.znorm;
-        if (2 * (k + 1) <= AR_THREADS) {   // two adjacent lanes per root: each sums every other pole
-            const int j = tid >> 1, sub = tid & 1;
-            if (j <= k) {
+        auto put = [&](int jr, int o, float t) {
+            org[jr] = o;
+            tau[jr] = t;
+            lamd[jr] = dl[o];
+            vals[jr] = dl[o] + t;
+        };
+        // Lanes per root: two adjacent lanes (each sums every other pole) while the roots fit, one otherwise; roots
+        // beyond the lanes' first pass -- root 128 of D = 128, root 256 of D = 256 -- are solved by the whole of
+        // wave 0 (each lane two to four poles) instead of a second, nearly empty pass.
+        const int first = (k + 1 <= AR_THREADS / 2 + 1) ? min(k + 1, AR_THREADS / 2) : min(k + 1, AR_THREADS);
+        if (first <= AR_THREADS / 2) {
+            const int jr = tid >> 1, sub = tid & 1;
+            if (jr < first) {
                 int o;
                 float t;
-                arrow_root(k, j, alpha, znorm, dl, zl, o, t, nullptr, sub, 2, [](float x) {
+                arrow_root(k, jr, alpha, znorm, dl, zl, o, t, nullptr, sub, 2, [](float x) {
                     return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1,
                                                                                        0xF, 0xF, false));   // quad_perm [1,0,3,2]
                 });
-                if (sub == 0) {
-                    org[j] = o;
-                    tau[j] = t;
-                    lamd[j] = dl[o];
-                    vals[j] = dl[o] + t;
-                }
+                if (sub == 0) put(jr, o, t);
             }
-        } else {
-            for (int j = tid; j <= k; j += AR_THREADS) {
+        } else if (tid < first) {
+            int o;
+            float t;
+            arrow_root(k, tid, alpha, znorm, dl, zl, o, t);
+            put(tid, o, t);
+        }
+        if (tid < 64) {
+            for (int jr = first; jr <= k; ++jr) {
                 int o;
                 float t;
-                arrow_root(k, j, alpha, znorm, dl, zl, o, t);
-                org[j] = o;
-                tau[j] = t;
-                lamd[j] = dl[o];
-                vals[j] = dl[o] + t;
+                arrow_root(k, jr, alpha, znorm, dl, zl, o, t, nullptr, tid, 64, [](float x) { return wave_sum(x); });
+                if (tid == 0) put(jr, o, t);
             }
         }
     }
