@@ -15,3 +15,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built_library():
+    """The tests exercise the in-tree C-ABI library: on a fresh checkout (the .so is not tracked) build it once,
+    exactly as `__graft_entry__.build()` does.  The PRODUCT never builds or falls back by itself -- `_lib.load()`
+    raises when the library is missing (tests/test_host_logic.py checks that)."""
+    from admm_net_amd import build as _build
+    if not os.path.exists(_build.LIB):
+        _build.build_extension()
+    return _build.LIB
+

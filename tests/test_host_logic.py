@@ -86,6 +86,13 @@ def test_bad_config_is_rejected():
     assert b"unsupported geometry" in lib.admmnet_last_error()
 
 
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "admm_net_amd", "no_such_library.so"))
+    with pytest.raises(_lib.AdmmNetError, match="There is no CPU fallback"):
+        _lib.load()
+
+
 def test_forward_without_gpu_fails_loudly():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
