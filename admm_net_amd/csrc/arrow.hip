@@ -210,7 +210,19 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
     __syncthreads();
     mark(1);
     // ---- P5: zeta-hat, final (ascending, stable) positions of all n eigenvalues
-    for (int i = tid; i < k; i += AR_THREADS) zh[i] = arrow_zhat(k, i, dl, lamd, tau);
+    {   // two adjacent lanes per pole (k <= 128): half of the serial product each
+        const int G = (2 * k <= AR_THREADS) ? 2 : 1;
+        const int sub = (G == 2) ? (tid & 1) : 0;
+        auto redm = [G](float x) {
+            const float y = __builtin_bit_cast(
+                float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+            return G == 2 ? x * y : x;
+        };
+        for (int i = (G == 2) ? (tid >> 1) : tid; i < k; i += AR_THREADS / G) {
+            const float v = arrow_zhat(k, i, dl, lamd, tau, sub, G, redm);
+            if (sub == 0) zh[i] = v;
+        }
+    }
     for (int s = tid; s < n; s += AR_THREADS) {
         const float v = vals[s];
         int r = 0;

@@ -181,17 +181,19 @@ HD float arrow_delta(FA d, FA lamd, FA tau, int i, int j) {
 }
 
 // Gu / Eisenstat zeta-hat_i (>= 0) from the computed roots
-template <class FA>
-HD float arrow_zhat(int k, int i, FA d, FA lamd, FA tau) {
+// (sub, G, red): a group of G adjacent lanes shares one i, `red` multiplies the partial products across it.
+template <class FA, class Red = ArrowNoReduce>
+HD float arrow_zhat(int k, int i, FA d, FA lamd, FA tau, int sub = 0, int G = 1, Red red = Red()) {
     const float di = d[i];
-    float w = ((di - lamd[i]) - tau[i]) * -((di - lamd[i + 1]) - tau[i + 1]);   // (d_i - lam_i)(lam_{i+1} - d_i)
+    float w = (sub == 0) ? ((di - lamd[i]) - tau[i]) * -((di - lamd[i + 1]) - tau[i + 1])   // (d_i - lam_i)(lam_{i+1} - d_i)
+                         : 1.0f;
 #pragma unroll 4
-    for (int j = 0; j < k; ++j) {
+    for (int j = sub; j < k; j += G) {
         const int jr = (j < i) ? j : j + 1;   // root paired with pole j
         const float q = fdiv_fast((di - lamd[jr]) - tau[jr], di - d[j]);
         w *= (j == i) ? 1.0f : q;
     }
-    return sqrtf(fabsf(w));
+    return sqrtf(fabsf(red(w)));
 }
 
 }  // namespace admmnet

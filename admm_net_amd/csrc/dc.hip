@@ -306,7 +306,19 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         mark(4);
         // P4: Loewner z-hat, final (ascending, stable) positions
         if (act) {
-            for (int i = tl; i < k; i += ts) zh[a + i] = lowner_zhat(k, i, dl + a, zl + a, org + a, tau + a);
+            {   // two adjacent lanes per pole while the team has them (as for the roots): half the serial product each
+                const int G = (2 * k <= ts) ? 2 : 1;
+                const int sub = (G == 2) ? (tl & 1) : 0;
+                auto redm = [G](float x) {
+                    const float y = __builtin_bit_cast(
+                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+                    return G == 2 ? x * y : x;
+                };
+                for (int i = (G == 2) ? (tl >> 1) : tl; i < k; i += ts / G) {
+                    const float v = lowner_zhat(k, i, dl + a, zl + a, org + a, tau + a, sub, G, redm);
+                    if (sub == 0) zh[a + i] = v;
+                }
+            }
             for (int p = tl; p < nn; p += ts) {
                 const float v = vals[a + p];
                 int r = 0;
@@ -326,14 +338,19 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         //     vectors themselves are regenerated inside the GEMM (two subtractions, a reciprocal and two
         //     products per entry, hidden under the MFMA) instead of making a round trip through memory.
         if (act) {
-            for (int j = tl; j < k; j += ts) {
+            const int G = (2 * k <= ts) ? 2 : 1;   // two lanes per root: each sums every other entry
+            const int sub = (G == 2) ? (tl & 1) : 0;
+            for (int j = (G == 2) ? (tl >> 1) : tl; j < k; j += ts / G) {
                 float nrm = 0.f;
                 const float dorg = dl[a + org[a + j]], tj = tau[a + j];
 #pragma unroll 4
-                for (int i = 0; i < k; ++i) {
+                for (int i = sub; i < k; i += G) {
                     const float u = fdiv_fast(zh[a + i], (dl[a + i] - dorg) - tj);
                     nrm = fmaf(u, u, nrm);
                 }
+                if (G == 2)
+                    nrm += __builtin_bit_cast(
+                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, nrm), 0xB1, 0xF, 0xF, false));
                 un[a + j] = 1.0f / sqrtf(nrm);
             }
         }

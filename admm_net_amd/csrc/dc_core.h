@@ -550,14 +550,17 @@ HD float dc_delta(FA d, IA org, FA tau, int i, int j) {
 // Gu / Eisenstat: z-hat_i = sign(z_i) sqrt( prod_j (lam_j - d_i) / prod_{j != i} (d_j - d_i) / rho ... )
 // with all differences taken from the COMPUTED roots, which makes the eigenvectors
 // u_j = (zhat_i / (d_i - lam_j))_i numerically orthogonal (LAPACK slaed3).
-template <class FA, class IA>
-HD float lowner_zhat(int k, int i, FA d, FA z, IA org, FA tau) {
-    float w = dc_delta(d, org, tau, i, i);   // d_i - lam_i
+// A group of G adjacent lanes may share one i: lane `sub` takes the factors j = sub, sub + G, ... and `red`
+// multiplies the partial products across the group (host / single lane: sub = 0, G = 1, identity).
+template <class FA, class IA, class Red = SecNoReduce>
+HD float lowner_zhat(int k, int i, FA d, FA z, IA org, FA tau, int sub = 0, int G = 1, Red red = Red()) {
+    float w = (sub == 0) ? dc_delta(d, org, tau, i, i) : 1.0f;   // d_i - lam_i
 #pragma unroll 4
-    for (int j = 0; j < k; ++j) {
+    for (int j = sub; j < k; j += G) {
         const float q = fdiv_fast(dc_delta(d, org, tau, i, j), d[i] - d[j]);
         w *= (j == i) ? 1.0f : q;
     }
+    w = red(w);
     const float r = sqrtf(fabsf(w));
     return z[i] >= 0.f ? r : -r;
 }
