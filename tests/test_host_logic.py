@@ -3,6 +3,7 @@ classical solver, peak search, and the host model of the eigensolver cores."""
 import ctypes
 import glob
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -336,6 +337,29 @@ def test_dc_model(dc_model, name):
     assert np.abs(W.T @ W - np.eye(n)).max() < 6e-6
     assert np.abs(lam - np.linalg.eigvalsh(T)).max() < 2e-6 * scale
     assert st[3] <= 25   # middle-way iteration: a handful of passes per root, bisection fallbacks are rare
+
+
+@pytest.mark.parametrize("n,nb", [(9, 4), (33, 8), (129, 16), (130, 32)])
+def test_panel_blocked_tridiagonalisation_model(n, nb):
+    """tests/host_model/latrd_model.py (groundwork for the matrix-core tridiagonalisation):
+    the panel-blocked reduction produces the same reflectors and the same T as the unblocked one the kernels
+    implement, and Q^H A Q = T."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "host_model"))
+    import latrd_model as L
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    A0 = (X + X.conj().T) / 2
+    A0[1:, 1:] = 0.3 * np.eye(n - 1) + 0.05 * A0[1:, 1:]          # arrow-first layer-like matrix: strong first row / column
+    d1, e1, V1, t1 = L.hetrd_unblocked(A0)
+    d2, e2, V2, t2 = L.hetrd_blocked(A0, nb)
+    scale = np.abs(A0).max()
+    assert np.abs(d1 - d2).max() < 1e-12 * scale and np.abs(e1 - e2).max() < 1e-12 * scale
+    assert np.abs(V1 - V2).max() < 1e-10 and np.abs(t1 - t2).max() < 1e-10
+    Q = L.form_q(V2, t2)
+    T = np.diag(d2) + np.diag(e2, 1) + np.diag(e2, -1)
+    assert np.abs(Q.conj().T @ A0 @ Q - T).max() < 1e-12 * scale
+    assert np.abs(Q.conj().T @ Q - np.eye(n)).max() < 1e-13
+    assert np.abs(np.sort(np.linalg.eigvalsh(T)) - np.linalg.eigvalsh(A0)).max() < 1e-12 * scale
 
 
 def test_team_deflation_scan_equals_serial_scan(dc_model):
