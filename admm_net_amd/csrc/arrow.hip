@@ -276,10 +276,16 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
     int *ipos = reinterpret_cast<int *>(hraw);   // inverse permutation (hraw is dead since P1)
     for (int p = tid; p < D; p += AR_THREADS) ipos[perm[p]] = p;
     __syncthreads();
-    for (int i = tid; i < Dp; i += AR_THREADS) {
+    // (when the plane is narrower than the workgroup, AR_THREADS / Dp threads share a column and split its
+    //  entries s: at D = 128 two threads per column instead of 128 idle ones)
+    const int nparts = (AR_THREADS / Dp > 0) ? AR_THREADS / Dp : 1;
+    const int sper = (n + nparts - 1) / nparts;
+    for (int it = tid; it < Dp * nparts; it += AR_THREADS) {
+        const int i = it % Dp, part = it / Dp;
+        const int s0 = part * sper, s1 = min(n, s0 + sper);
         float *colr = VTl + i, *coli = VTl + Dp + i;
         if (i >= D) {
-            for (int c = 0; c < n; ++c) {
+            for (int c = s0; c < s1; ++c) {
                 colr[c * VP] = 0.f;
                 coli[c * VP] = 0.f;
             }
@@ -289,15 +295,15 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
         if (kd >= 0) {   // surviving pole kd: component zhat x0_s / (lam_s - d) in every root's eigenvector
             const float zi = zh[kd], di = dl[kd];
 #pragma unroll 4
-            for (int s = 0; s <= k; ++s) {
+            for (int s = s0; s < min(s1, k + 1); ++s) {
                 const float v = fdiv_fast(zi, (lamd[s] - di) + tau[s]) * x0[s];
                 colr[rnk[s] * VP] = v;
             }
-            for (int s = k + 1; s < n; ++s) colr[rnk[s] * VP] = 0.f;
+            for (int s = max(s0, k + 1); s < s1; ++s) colr[rnk[s] * VP] = 0.f;
         } else {         // deflated pole: unit vector of slot -(kd) - 1
             const int slot = -kd - 1;
 #pragma unroll 4
-            for (int s = 0; s < n; ++s) colr[rnk[s] * VP] = (s == slot) ? 1.f : 0.f;
+            for (int s = s0; s < s1; ++s) colr[rnk[s] * VP] = (s == slot) ? 1.f : 0.f;
         }
     }
     __syncthreads();
@@ -314,11 +320,13 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
     }
     __syncthreads();
     // phases: (re, im) planes
-    for (int i = tid; i < D; i += AR_THREADS) {
+    for (int it = tid; it < Dp * nparts; it += AR_THREADS) {
+        const int i = it % Dp, part = it / Dp;
+        if (i >= D) continue;
         float *colr = VTl + i, *coli = VTl + Dp + i;
         const float pr = phr[i], pi = phim[i];
 #pragma unroll 8
-        for (int c = 0; c < n; ++c) {
+        for (int c = part * sper; c < min(n, (part + 1) * sper); ++c) {
             const float x = colr[c * VP];
             colr[c * VP] = x * pr;
             coli[c * VP] = x * pi;
