@@ -130,3 +130,26 @@ def admm_for_us(y, b, xbase, ybase, lambda_val, sigma, opts=None, use_min_iter=T
                 print(f"退出admm迭代，当前迭代次数为: {iter_count}")
                 break
     return phiK, iter_count
+
+
+def cfg1_scene(sig, e, seed=0, snr_w=20.0):
+    """The fixed 10 x 10 demo scene of /root/reference/main.py:11-86 with ``data_type = 2`` (QPSK symbols ``sig`` and
+    demodulation errors ``e`` taken from data/data.npz, :62-70): three targets, ``Psi = kr(S, conj D) C`` (:15-29),
+    ``b = sig - e``, ``y = diag(b + e) Psi + w`` at 20 dB (:73-77), ``sigma = ||e / b|| + 1`` (:81).  Only the noise
+    draw is seeded (the reference seeds nothing).  Returns (y [100, 1], b [100], sigma) as main.py passes them."""
+    from .synth import steering
+    Nb = Nd = 10
+    f = np.array([-0.25, 0, 0.14])
+    tau = np.array([0.45, 0.25, 0.63])
+    C = np.array([-0.5 + 1j, 0.6 - 0.2j, 0.3 + 0.7j])
+    S, Dm = steering(f, Nb), steering(tau, Nd)                                   # [L, Nb], [L, Nd]
+    Psi = np.einsum("l,li,lj->ij", C, S, np.conj(Dm)).reshape(Nb * Nd, 1)       # kr(S, conj D) @ C
+    sig, e = np.asarray(sig).reshape(-1), np.asarray(e).reshape(-1)
+    b = sig - e
+    real_y = np.diag(b + e) @ Psi
+    rng = np.random.default_rng(seed)
+    w = np.sqrt(1 / 2) * (rng.standard_normal((Nb * Nd, 1)) + 1j * rng.standard_normal((Nb * Nd, 1)))
+    w_var = np.linalg.norm(real_y) ** 2 / (10 ** (snr_w / 10) * Nb * Nd)
+    y = real_y + np.sqrt(w_var) * w
+    sigma = np.linalg.norm(e / b) + 1
+    return y, b, sigma

@@ -602,4 +602,16 @@ int admmnet_peak_search_f64(const void *phi, int64_t B, int32_t xbase, int32_t y
                         peaks, counts, st);
 }
 
+int admmnet_regional_maxima_f64(const double *Z, int64_t B, int32_t nx, int32_t ny, int32_t max_peaks,
+                                double *peaks, int32_t *counts, void *stream) {
+    if (!Z || B < 1 || nx < 1 || ny < 1 || max_peaks < 1 || !peaks || !counts) {
+        set_error("regional maxima: bad argument");
+        return ADMMNET_E_ARG;
+    }
+    const double o7[7] = {0, 0, 0, 0, 0, 0, 0};
+    // the maxima stage of the peak-search kernel alone: no phi, no axes (positions = pixel column / row), no rounds
+    return launch_peaks(nullptr, B, 1, 1, Z, nx, ny, nullptr, nullptr, o7, 0, max_peaks, peaks, counts,
+                        (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -91,16 +91,21 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
         sh.mx[0] = __float_as_int(fabsf(alpha));
         sh.mx[1] = 0;
     }
+    int bad = 0;   // non-finite input or eigenvalue: reported through status[0] (torch.linalg.eigh raises on such input)
     for (int i = tid; i < D; i += AR_THREADS) {
         const float2 z = phi[b * D + i];
         const float a = sqrtf(z.x * z.x + z.y * z.y);
         const float ia = a > 0.f ? 1.0f / a : 0.f;
         hraw[i] = h[b * D + i];
+        bad |= !(isfinite(a) && isfinite(hraw[i]));
         zraw[i] = a;
         phr[i] = a > 0.f ? z.x * ia : 1.f;
         phim[i] = a > 0.f ? z.y * ia : 0.f;
     }
-    __syncthreads();
+    if (__syncthreads_or(bad)) {   // NaN / Inf input: the rank sort below would leave permutation slots unwritten
+        if (tid == 0 && status) atomicAdd(status, 1);
+        return;
+    }
     // ---- P1: sort h ascending (stable rank counting)
     for (int i = tid; i < D; i += AR_THREADS) {
         const float v = hraw[i];
@@ -208,6 +213,7 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
         }
     }
     __syncthreads();
+    for (int p = tid; p < n; p += AR_THREADS) bad |= !isfinite(vals[p]);
     mark(1);
     // ---- P5: zeta-hat, final (ascending, stable) positions of all n eigenvalues
     {   // two adjacent lanes per pole (k <= 128): half of the serial product each
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(AR_THREADS, 1) void arrow_rebuild_kernel(
     }
     __syncthreads();
     mark(3);
-    (void)status;
+    if (__syncthreads_or(bad) && tid == 0 && status) atomicAdd(status, 1);
     if constexpr (BIG) return;
     else rebuild_from_lds(g, b, lw, VTl, fs, w0f, z0s, rowb, redb, phi, h, G, rn, [&](int id) { mark(id); }, lower_only);
 }

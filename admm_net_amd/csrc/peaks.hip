@@ -83,8 +83,8 @@ __global__ __launch_bounds__(PK_THREADS) void peaks_kernel(const float2 *__restr
     const int64_t b = blockIdx.x;
     const double *Zb = Z + b * (int64_t)npix;
     for (int i = tid; i < npix; i += PK_THREADS) img[i] = Zb[i];
-    for (int i = tid; i < D; i += PK_THREADS) {
-        const float2 p = phi[b * D + i];
+    for (int i = tid; i < D; i += PK_THREADS) {   // (phi == nullptr: maxima of a caller-supplied image, no refinement)
+        const float2 p = phi ? phi[b * D + i] : make_float2(0.f, 0.f);
         ph[i] = make_double2((double)p.x, (double)p.y);
     }
     __syncthreads();
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(PK_THREADS) void peaks_kernel(const float2 *__restr
     for (int k = wave; k < npk; k += PK_THREADS / 64) {
         const int pix = plist[k];
         const int r = pix / nx, c = pix - r * nx;
-        double px = axis_x[c], py = axis_y[r], height = 0.0;
+        double px = axis_x ? axis_x[c] : (double)c, py = axis_y ? axis_y[r] : (double)r, height = 0.0;
         double lx = o.xstep, ly = o.ystep;
         for (int it = 0; it < o.iters; ++it) {
             lx = o.reduce * lx;

@@ -1,4 +1,5 @@
-"""Shim for ``from utils.mathUtils import *``: signal-model helpers the demo scripts call."""
+"""Shim for ``from utils.mathUtils import *``: signal-model helpers the demo scripts call (same five names as
+utils/mathUtils.py plus ``np``, which star-importers of the reference module also receive)."""
 import numpy as np
 
 

@@ -142,3 +142,26 @@ def peak_search(phi: torch.Tensor, xbase: int, ybase: int, opts=None, max_peaks:
                                                int(so["iter"]), max_peaks, _ptr(peaks), _ptr(counts), _ptr(ws), need,
                                                _stream(dev)), "admmnet_peak_search_f64")
     return peaks, counts
+
+
+def regional_maxima(Z: torch.Tensor):
+    """skimage.morphology.local_maxima(connectivity=2) (utils/peakSearchUtils.py:118) of a batch of images on the
+    device (the maxima stage of the peak-search kernel).  Z [B, ny, nx] float64 -> bool mask [B, ny, nx]."""
+    _need_cuda(Z, "Z")
+    lib = _lib.load()
+    dev = Z.device
+    Z = Z.to(torch.float64).contiguous()
+    B, ny, nx = Z.shape
+    cap = nx * ny
+    with torch.cuda.device(dev):
+        peaks = torch.zeros(B, cap, 3, dtype=torch.float64, device=dev)
+        counts = torch.zeros(B, dtype=torch.int32, device=dev)
+        _lib.check(lib.admmnet_regional_maxima_f64(_ptr(Z), B, nx, ny, cap, _ptr(peaks), _ptr(counts), _stream(dev)),
+                   "admmnet_regional_maxima_f64")
+    mask = torch.zeros(B, ny, nx, dtype=torch.bool, device=dev)
+    cnt = counts.cpu()
+    for i in range(B):
+        k = int(cnt[i])
+        if k:
+            mask[i, peaks[i, :k, 1].long(), peaks[i, :k, 0].long()] = True
+    return mask

@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: signals/sec of the K-layer ADMM-Net forward on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg3|ref]
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+    python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|cfg5|ref]
+    (N > 1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks are already there; a plain
+     `python bench.py --gpus N` starts them itself as child processes and relays rank 0's line.)
+
+Default workload = cfg3, the configuration BASELINE.json's metric is quoted on (K=16, 16x16 grid -> D=256,
+n=257, batch 65536 per GPU, spectrum on 1024 atoms); cfg2 = configs[1]; cfg5 = K=32 PhiEstADMMNet followed by
+the classical grid peak search on a 2048-atom coarse grid inside the timed step.
 
 One "step" = the whole hot path on one resident synthetic batch: ADMMNet forward (K unrolled layers
 + learned peak head) followed by the batch x steering-dictionary spectrum on Natoms (tau, f) atoms.
@@ -32,9 +37,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 WORKLOADS = {
-    # name: (Nb, Nd, K, batch per GPU, tau atoms, f atoms)   -- BASELINE.json configs[1] / [2], SURVEY section 0
+    # name: (Nb, Nd, K, batch per GPU, tau atoms, f atoms)   -- BASELINE.json configs[1] / [2] / [4], SURVEY section 0
     "cfg2": (8, 16, 8, 4096, 32, 16),
     "cfg3": (16, 16, 16, 65536, 32, 32),
+    "cfg5": (16, 16, 32, 65536, 64, 32),     # PhiEstADMMNet + alt_peak_search post-processing (main_for_net.py:99-126)
     "ref": (10, 10, 10, 4096, 32, 16),
 }
 # kernel classes of admmnet_profile_read (include/admmnet.h): "trideig" = tridiagonal eigensolver
@@ -47,17 +53,18 @@ def flops_per_signal(K, n, D, natoms):
     return (K - 1) * 24.0 * n ** 3 + K * 256.0 * D + 8.0 * D * natoms
 
 
-def measured_traffic(workload, kernel, B):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic.json: rocprofv3 --pmc
-    FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this script, FETCH_SIZE doubled as the gfx950 guide
-    prescribes).  None when there is no measurement for this workload / kernel / batch."""
+def measured_counters(workload, kernel, mats_per_launch):
+    """(HBM bytes per launch, MFMA-busy fraction) of `kernel` from the committed PMC passes (profiles/traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_* in separate runs of this script, FETCH_SIZE doubled as the
+    gfx950 guide prescribes).  Entries are keyed by workload and recorded per matrix, so a launch over
+    `mats_per_launch` matrices scales them.  (None, None) when there is no measurement for this workload / kernel."""
     try:
         t = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
-        if t.get("workload") != workload or B != t.get("batch", 4096):
-            return None
-        return t["kernels"][kernel]["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+        e = t["workloads"][workload]["kernels"][kernel]
+        tr = e.get("traffic_bytes_per_matrix")
+        return (None if tr is None else tr * mats_per_launch), e.get("mfma_busy")
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None
 
 
 def kernel_flops_per_matrix(n):
@@ -89,12 +96,26 @@ def host_threads():
     return max(1, min(n, int(os.environ.get("ADMMNET_CPU_THREADS", "64"))))
 
 
+def spawn_ranks(n):
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching %d ranks: %s" % (n, " ".join(cmd)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -102,8 +123,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        sys.exit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as CHILD processes (nothing here has touched the GPU
+        # yet, and nothing is exec'ed over this process), relay their output and exit with their status
+        sys.exit(spawn_ranks(args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     local = local % torch.cuda.device_count()     # (rehearsals put several ranks on one GPU)
@@ -124,24 +147,39 @@ def main():
     if args.batch:
         B = args.batch
     D, n, natoms = Nb * Nd, Nb * Nd + 1, ntau * nf
+    post_search = args.workload == "cfg5"     # PhiEst inference + classical peak search instead of head + spectrum
     torch.manual_seed(0)
-    model = A.ADMMNet(M=Nb, N=Nd, L=3, num_layers=K).eval()      # random init of the reference architecture
+    cls = A.PhiEstADMMNet if post_search else A.ADMMNet
+    model = cls(M=Nb, N=Nd, L=3, num_layers=K).eval()            # random init of the reference architecture
     y, b, s, _ = synth.make_batch(B, Nb, Nd, seed=20260104 + rank)
     ty, tb, ts = (torch.from_numpy(v).to(dev) for v in (y, b, s))
     taus = torch.linspace(0.0, 1.0, ntau + 1, dtype=torch.float64)[:-1].to(dev)
     fs = torch.linspace(-0.5, 0.5, nf + 1, dtype=torch.float64)[:-1].to(dev)
+    # cfg5: alt_peak_search's own coarse grid (np.arange(0, 1 - xstep, xstep) x np.arange(-.5, .5 - xstep, ystep),
+    # peakSearchUtils.py:105-106) sized to ntau x nf atoms, two refinement rounds
+    ps_opts = {"xstep": 1.0 / (ntau + 1), "ystep": 1.0 / nf, "iter": 2}
+    if post_search:
+        from admm_net_amd import peak_search as ps
+        ax, ay = ps.coarse_axes(ps_opts)
+        assert len(ax) * len(ay) == natoms, (len(ax), len(ay), natoms)
     sf = sharded.ShardedForward(model, scope="global")
     lib = _lib.load()
 
     def step():
         if world > 1:
             phi, head = sf(ty, tb, ts)
-            spec = ops.spectrum(phi, Nd, Nb, taus, fs)      # xbase = Nd (delay), ybase = Nb (Doppler)
-            gathered = sf._gather(head, dim=1)                      # final peak output over RCCL / xGMI
-            return phi, gathered, spec
-        tau, f, conf, phi = model(ty, tb, ts)
-        spec = ops.spectrum(phi, Nd, Nb, taus, fs)      # xbase = Nd (delay), ybase = Nb (Doppler)
-        return phi, (tau, f, conf), spec
+        else:
+            out = model(ty, tb, ts)
+            phi, head = (out, None) if post_search else (out[3], torch.stack(out[:3]))
+        if post_search:
+            pk, cnt = ops.peak_search(phi, Nd, Nb, ps_opts, max_peaks=64)     # xbase = Nd (delay), ybase = Nb (Doppler)
+            tail = pk[:, :8].contiguous()                                      # the peak list is the final output
+        else:
+            spec = ops.spectrum(phi, Nd, Nb, taus, fs)
+            tail = head
+        if world > 1:
+            tail = sf._gather(tail, dim=0 if post_search else 1)               # final peak output over RCCL / xGMI
+        return phi, tail
 
     log(f"workload {args.workload}: grid {Nb}x{Nd} K={K} B={B}/GPU world={world}; warmup x{args.warmup}")
     for _ in range(args.warmup):
@@ -167,10 +205,15 @@ def main():
     cnt = (ctypes.c_int64 * 8)()
     _lib.check(lib.admmnet_profile_read(ms, cnt, 8), "admmnet_profile_read")
     lib.admmnet_profile_enable(0)
+    ranks = 1
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        one = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)          # ranks that actually took part in the collective
+        ranks = int(one.item())
+        assert ranks == dist.get_world_size() == world
     assert torch.isfinite(torch.view_as_real(out[0])).all()
 
     if rank == 0:
@@ -185,9 +228,10 @@ def main():
         avg_ms = per[dom][0] / launches
         mats_per_launch = B / math.ceil(B / chunk)          # every launch of an eigen-kernel works on one chunk
         ach = kf * mats_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic, mfma_busy = measured_counters(args.workload, dom, mats_per_launch)
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 5),
-                "traffic": measured_traffic(args.workload, dom, B),
+                "traffic": traffic, "mfma_busy": mfma_busy,
                 "avg_launch_ms": round(avg_ms, 4), "matrices_per_launch": mats_per_launch,
                 "flops_per_matrix": kf,
                 "end_to_end_tflops": round(F * value / world / 1e12, 3),
@@ -195,13 +239,16 @@ def main():
                 "kernel_ms_per_step": {k_: round(v[0] / args.steps, 3) for k_, v in per.items()}}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(model, Nb, Nd, K, y, b, s, out[0], args.workload)
+            cpu = cpu_baseline(model, Nb, Nd, K, y, b, s, out[0], args.workload, head=not post_search)
+            cpu["classical"] = classical_baseline()
         line = {"metric": "signals/sec (K-layer ADMM-Net forward)", "value": round(value, 2), "unit": "signals/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "n_gpus": ranks if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"{args.workload}: ADMMNet K={K} grid {Nb}x{Nd} (D={D}, n={n}) "
-                                       f"batch {B}/GPU + spectrum on {natoms} atoms",
+                "config": {"workload": (f"{args.workload}: PhiEstADMMNet K={K} grid {Nb}x{Nd} (D={D}, n={n}) batch {B}/GPU "
+                                        f"+ alt_peak_search on a {natoms}-atom coarse grid" if post_search else
+                                        f"{args.workload}: ADMMNet K={K} grid {Nb}x{Nd} (D={D}, n={n}) "
+                                        f"batch {B}/GPU + spectrum on {natoms} atoms"),
                            "batch_per_gpu": B, "global_batch": B * world, "K": K, "D": D, "n": n,
                            "natoms": natoms, "batch_mean_scope": "global", "chunk": chunk,
                            "weights": "torch.manual_seed(0) default init"},
@@ -212,7 +259,32 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(model, Nb, Nd, K, y, b, s, phi_gpu, workload):
+def classical_baseline():
+    """cfg1 (BASELINE.json configs[0]): the classical solver admm_for_us on the data/data.npz scene of main.py:51-95
+    (fixture tests/golden/cfg1_data.npz holds the two arrays of that file), CPU, complex128, single signal -- wall
+    time beside the published mean of results/time/time.txt."""
+    import contextlib
+    import io
+    from admm_net_amd import classical
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cfg1_data.npz"), allow_pickle=False)
+    opts = {"eta_abs": 1e-7, "eta_rel": 1e-7, "max_iter": 100}                  # main.py:88-93
+    ts, it = [], 0
+    from threadpoolctl import threadpool_limits
+    # one BLAS thread: at n = 101 the threaded SVD of scipy only spins (26x slower on 8 threads in the build container)
+    with contextlib.redirect_stdout(io.StringIO()), threadpool_limits(limits=1):   # admm_for_us prints, as the reference does
+        for r in range(21):                                                     # first run = warm-up, as test_time_admm.py
+            y, b, sigma = classical.cfg1_scene(z["sig"], z["e"], seed=r)
+            t0 = time.perf_counter()
+            phi, it = classical.admm_for_us(y, b, 10, 10, 1, sigma, opts)
+            if r:
+                ts.append(time.perf_counter() - t0)
+    return {"seconds_per_signal": round(float(np.mean(ts)), 6), "iterations": int(it), "runs": len(ts),
+            "published_reference_seconds": 0.5244,
+            "note": "admm_net_amd.classical.admm_for_us on the main.py data.npz scene (D=100), 1 core; "
+                    "published = mean of /root/reference/results/time/time.txt (hardware unstated)"}
+
+
+def cpu_baseline(model, Nb, Nd, K, y, b, s, phi_gpu, workload, head=True):
     """Oracle (torch CPU restatement of admm_net.py, kind = 'port') on a bounded sample of the same
     workload; also re-checks parity of the benchmarked batch on that sample."""
     from oracle import admm_net_ref as R
@@ -224,7 +296,7 @@ def cpu_baseline(model, Nb, Nd, K, y, b, s, phi_gpu, workload):
     def run(nsig):
         ty, tb, ts = torch.from_numpy(y[:nsig]), torch.from_numpy(b[:nsig]), torch.from_numpy(s[:nsig])
         t0 = time.perf_counter()
-        out = R.forward(sd, ty, tb, ts, Nb, Nd, K, dtype="f32", head=True)
+        out = R.forward(sd, ty, tb, ts, Nb, Nd, K, dtype="f32", head=head)
         return time.perf_counter() - t0, out
     t_probe, _ = run(16)
     log(f"cpu probe: 16 signals in {t_probe:.2f} s")

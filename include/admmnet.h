@@ -178,6 +178,14 @@ int admmnet_peak_search_f64(const void *phi, int64_t B, int32_t xbase, int32_t y
                             const double *opts7, int32_t iters, int32_t max_peaks, double *peaks,
                             int32_t *counts, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The regional-maxima stage of that kernel alone, on caller-supplied images: skimage.morphology.local_maxima(
+ * connectivity=2) as used at utils/peakSearchUtils.py:118 (8-connected, plateau aware, borders allowed, a constant
+ * image has none; the reference's own example input is the plateau matrix at :427-432).
+ *   Z device float64 [B][ny][nx];  peaks device float64 [B][max_peaks][3] = (column, row, 0) of every maximum
+ *   pixel in np.where row-major order;  counts device int32 [B]. */
+int admmnet_regional_maxima_f64(const double *Z, int64_t B, int32_t nx, int32_t ny, int32_t max_peaks,
+                                double *peaks, int32_t *counts, void *stream);
+
 /* ---- measurement hooks (bench.py roofline leg) ---------------------------------
  * When enabled, every kernel launcher brackets its launch with HIP events on the
  * caller's stream.  admmnet_profile_read synchronises those events, returns the

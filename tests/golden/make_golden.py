@@ -26,16 +26,8 @@ import torch
 
 import admm_net as ref  # the reference module (imported, not copied)
 from admm_net_amd.synth import make_batch
-
-
-def perturb_(model, seed):
-    g = torch.Generator().manual_seed(seed)
-    with torch.no_grad():
-        for name, p in model.named_parameters():
-            if p.dim() == 0:
-                p.add_(0.5 * torch.randn((), generator=g))
-            elif "in_proj_bias" in name or "out_proj.bias" in name:
-                p.add_(0.1 * torch.randn(p.shape, generator=g))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..")))
+from golden_util import checksum, perturb_   # shared with the loader: same perturbation recipe
 
 
 def sd_arrays(model):
@@ -43,7 +35,7 @@ def sd_arrays(model):
 
 
 @torch.no_grad()
-def run_case(name, cls, Nb, Nd, K, B, seed, perturbed, per_layer, sigma_2d):
+def run_case(name, cls, Nb, Nd, K, B, seed, perturbed, per_layer, sigma_2d, store_weights=True):
     torch.manual_seed(seed)
     model = getattr(ref, cls)(M=Nb, N=Nd, L=3, num_layers=K)
     if perturbed:
@@ -74,7 +66,12 @@ def run_case(name, cls, Nb, Nd, K, B, seed, perturbed, per_layer, sigma_2d):
             rec[f"L{k}:G"] = G.numpy()
             rec[f"L{k}:Z"] = Z.numpy()
         assert torch.equal(phi, out if cls != "ADMMNet" else out[3])
-    rec.update(sd_arrays(model))
+    if store_weights:
+        rec.update(sd_arrays(model))
+    else:   # deep 16x16 cases: weights by recipe (seed) + checksums of the reference's tensors (golden_util.py)
+        rec["wseed"] = np.array([seed, int(perturbed)])
+        for k, v in model.state_dict().items():
+            rec["wsum:" + k] = checksum(v)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **rec)
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
@@ -97,7 +94,18 @@ def split_batch_case():
     print("split_batch: max|full-split| =", np.abs(full - rec["phi_split"]).max())
 
 
+def depth_cases():
+    """Fixtures at the depth of the BASELINE configs (cfg2: K = 8 on 8x16; cfg3/4: K = 16 on 16x16; cfg5: K = 32)."""
+    run_case("phiest_8x16_K8_perturbed", "PhiEstADMMNet", 8, 16, 8, 3, 21, True, False, False)
+    run_case("phiest_16x16_K16_default", "PhiEstADMMNet", 16, 16, 16, 2, 22, False, False, False, store_weights=False)
+    run_case("phiest_16x16_K16_perturbed", "PhiEstADMMNet", 16, 16, 16, 2, 23, True, False, True, store_weights=False)
+    run_case("phiest_16x16_K32_default", "PhiEstADMMNet", 16, 16, 32, 1, 24, False, False, False, store_weights=False)
+
+
 if __name__ == "__main__":
+    if "--depth-only" in sys.argv:
+        depth_cases()
+        sys.exit(0)
     run_case("phiest_3x3_K3_default", "PhiEstADMMNet", 3, 3, 3, 3, 11, False, True, False)
     run_case("phiest_3x3_K3_perturbed", "PhiEstADMMNet", 3, 3, 3, 3, 12, True, True, True)
     run_case("phiest_4x4_K4_perturbed", "PhiEstADMMNet", 4, 4, 4, 3, 13, True, True, False)
@@ -109,3 +117,4 @@ if __name__ == "__main__":
     run_case("phiest_16x16_K2_default", "PhiEstADMMNet", 16, 16, 2, 2, 19, False, False, False)
     run_case("phiest_16x16_K3_perturbed", "PhiEstADMMNet", 16, 16, 3, 2, 20, True, False, False)
     split_batch_case()
+    depth_cases()

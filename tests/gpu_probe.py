@@ -47,9 +47,9 @@ def eigh_check():
 
 
 def load_case(p):
-    z = np.load(p)
-    Nb, Nd, K, B, L, head, s2d = [int(v) for v in z["meta"]]
-    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_util import load_fixture
+    z, sd, (Nb, Nd, K, B, L, head, _) = load_fixture(p)
     cls = A.ADMMNet if head else A.PhiEstADMMNet
     m = cls(M=Nb, N=Nd, L=L, num_layers=K)
     m.load_state_dict(sd)
@@ -61,7 +61,7 @@ def golden_check():
     section("forward vs golden fixtures (reference outputs)")
     for p in sorted(glob.glob(os.path.join(ROOT, "tests/golden/*.npz"))):
         name = os.path.basename(p)
-        if "split" in name:
+        if not name.startswith(("phiest_", "admmnet_")):
             continue
         z, m, sd, (Nb, Nd, K, B, L, head) = load_case(p)
         y, b, s = torch.from_numpy(z["y"]), torch.from_numpy(z["b"]), torch.from_numpy(z["sigma"])

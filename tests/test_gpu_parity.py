@@ -20,10 +20,12 @@ import torch
 import admm_net_amd as A
 from admm_net_amd import _lib, ops, peak_search, sharded, synth
 from oracle import admm_net_ref as R
+from golden_util import load_fixture
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-GOLD = sorted(p for p in glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")) if "split" not in p)
+GOLD = sorted(p for p in glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz"))
+              if os.path.basename(p).startswith(("phiest_", "admmnet_")))
 TOL_PHI = 1e-4
 
 
@@ -35,9 +37,7 @@ def dev():
 
 
 def load_case(p):
-    z = np.load(p)
-    Nb, Nd, K, B, L, head, s2d = [int(v) for v in z["meta"]]
-    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    z, sd, (Nb, Nd, K, B, L, head, s2d) = load_fixture(p)
     m = (A.ADMMNet if head else A.PhiEstADMMNet)(M=Nb, N=Nd, L=L, num_layers=K)
     m.load_state_dict(sd)
     return z, m.eval(), sd, (Nb, Nd, K, B, L, head, s2d)
@@ -232,12 +232,25 @@ def test_degenerate_inputs_match_oracle(dev, geom):
             assert np.abs(got[i] - ref[i]).max() <= 2e-4 * den + 1e-12, (i, np.abs(got[i] - ref[i]).max(), den)
 
 
-def test_fails_loudly_on_nonfinite_input(dev):
-    m = A.PhiEstADMMNet(M=3, N=3, num_layers=3).eval()
-    y, b, s, _ = synth.make_batch(2, 3, 3, seed=1)
-    y[0, 0] = np.nan
+@pytest.mark.parametrize("K", [2, 3])
+@pytest.mark.parametrize("geom", [(3, 3), (16, 16)])
+def test_fails_loudly_on_nonfinite_input(dev, K, geom):
+    """torch.linalg.eigh raises on non-finite input (admm_net.py:303); so must every eigen-path: K = 2 has the arrowhead
+    solver as its ONLY G-layer (arrow.hip), K = 3 adds a dense layer; 16x16 takes the D > 128 kernels."""
+    Nb, Nd = geom
+    m = A.PhiEstADMMNet(M=Nb, N=Nd, num_layers=K).eval()
+    y, b, s, _ = synth.make_batch(2, Nb, Nd, seed=1)
+    for bad in (np.nan, np.inf):
+        yy = y.copy()
+        yy[0, 0] = bad
+        with pytest.raises(_lib.AdmmNetError):
+            m(torch.from_numpy(yy).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(s).to(dev))
+    # and the single G-layer entry point with Z = None (arrowhead path)
+    phi = torch.from_numpy(y[:, :]).to(dev)
+    h = torch.rand(2, Nb * Nd, device=dev)
+    h[1, 2] = float("nan")
     with pytest.raises(_lib.AdmmNetError):
-        m(torch.from_numpy(y).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(s).to(dev))
+        ops.glayer(m, 0, phi, h, None)
 
 
 def test_bad_shapes_raise(dev):
@@ -294,19 +307,27 @@ def test_cfg3_shape_small_batch(dev):
     phi = m(ty.to(dev), tb.to(dev), ts.to(dev)).cpu().numpy()
     o32 = R.forward(sd, ty, tb, ts, Nb, Nd, K, dtype="f32").numpy()
     o64 = R.forward(sd, ty, tb, ts, Nb, Nd, K, dtype="f64").numpy()
-    # 15 dense 257x257 eigen-functions deep, fp32 arithmetic itself is the limit: the reference's own
-    # fp32 evaluation sits 4e-5 .. 1e-4 (seed dependent) from the float64 value of the same formulas, and
-    # two correct fp32 implementations land at different points of that cloud.  Stated tolerance for
-    # this depth: 5e-4 relative, against both the fp32 restatement and the float64 ground truth.
-    TOL_DEEP = 5e-4
-    ref_err = rel(o32, o64)
-    assert ref_err < TOL_DEEP                      # sanity of the yardstick itself
-    assert rel(phi, o64) <= TOL_DEEP
-    assert rel(phi, o32) <= TOL_DEEP
+    # 15 dense 257x257 eigen-functions deep: same bounds as every other case -- no further from float64 than 3x the
+    # reference arithmetic's own distance (+2e-6), and 1e-4-class against the fp32 evaluation.  (tests/gpu_bisect_cfg3.py
+    # shows each G-layer of this case, fed identical inputs, is as close to float64 as LAPACK's fp32 eigh: 2e-7 .. 5e-6.)
+    assert rel(phi, o64) <= 3 * rel(o32, o64) + 2e-6
+    assert rel(phi, o32) <= 2 * TOL_PHI
 
 
 # ------------------------------------------------------------------ spectrum / peak search
+# Expected values come from oracle/peak_search_ref.py: the LITERAL restatement of utils/peakSearchUtils.py (one
+# kron + dot per grid point, flood-fill regional maxima).  skimage is not installed here and the reference records
+# no expected outputs, so parity with skimage.local_maxima itself is UNPINNED (definition-level only).
+from oracle import peak_search_ref as PO   # noqa: E402
+
+
+def _top(rows, k=3):
+    return rows[np.argsort(-rows[:, 2], kind="stable")][:k]
+
+
 def test_spectrum_and_peak_indices(dev):
+    """ops.spectrum against the literal double loop (peakSearchUtils.py:37-60) and the regional-maxima indices of
+    both images (bit-exact), then the whole device peak search against alt_peak_search as written (:63-173)."""
     Nb = Nd = 10
     y, b, s, truth = synth.make_batch(4, Nb, Nd, seed=11, snr_range=(20.0, 20.0))
     torch.manual_seed(1)
@@ -314,26 +335,28 @@ def test_spectrum_and_peak_indices(dev):
     phi = m(torch.from_numpy(y).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(s).to(dev))
     opts = {"xstep": 1 / (10 * Nd), "ystep": 1 / (10 * Nb), "iter": 3}        # main_for_net.py:112-116
     ax, ay = peak_search.coarse_axes(opts)
-    Zg = ops.spectrum(phi, Nb, Nd, torch.from_numpy(ax), torch.from_numpy(ay)).cpu().numpy()
+    Zg = ops.spectrum(phi, Nb, Nd, torch.from_numpy(ax), torch.from_numpy(ay))
+    mask_dev = ops.regional_maxima(Zg).cpu().numpy()
+    Zg = Zg.cpu().numpy()
     ph = phi.cpu().numpy()
-    for i in range(4):
-        Zh = peak_search.spectrum_grid(ph[i], ax, Nb, ay, Nd)
-        assert np.abs(Zg[i] - Zh).max() < 1e-10 * Zh.max()
-        assert np.array_equal(peak_search.regional_maxima(Zg[i]), peak_search.regional_maxima(Zh))   # indices bit-exact
+    X, Y = np.meshgrid(ax, ay)
     got = peak_search.batched_peak_search(phi, Nb, Nd, opts, top=3)
     for i in range(4):
-        host = peak_search.alt_peak_search({"phi": ph[i], "xbase": Nb, "ybase": Nd}, opts)
-        host = host[np.argsort(-host[:, 2], kind="stable")][:3]
-        assert np.array_equal(got[i][:, :2], host[:, :2])
+        Zo = PO.peak_search(ph[i].astype(np.complex128), X, Nb, Y, Nd)          # oracle: 99 x 99 kron + dot
+        assert np.abs(Zg[i] - Zo).max() < 1e-10 * Zo.max()
+        want = PO.regional_maxima_floodfill(Zo)
+        assert np.array_equal(mask_dev[i], want)                                 # indices bit-exact
+        assert np.array_equal(PO.regional_maxima_floodfill(Zg[i]), want)
+        host = _top(PO.alt_peak_search_literal({"phi": ph[i].astype(np.complex128), "xbase": Nb, "ybase": Nd}, opts))
+        assert np.array_equal(got[i][:, :2], host[:, :2])                        # refined (tau, f) bit-exact
         assert np.abs(got[i][:, 2] - host[:, 2]).max() < 1e-9 * host[:, 2].max()
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("geom", [(10, 10, 1), (8, 16, 2), (16, 16, 1)], ids=["10x10", "8x16", "16x16"])
-def test_device_peak_search_matches_host(dev, geom):
-    """ops.peak_search (spectrum + regional maxima + refinement on the device, peaks.hip) against the host
-    mirror of alt_peak_search on the same phi: same maxima in the same (np.where) order, coordinates bit-exact,
-    heights to float64 rounding."""
+def test_device_peak_search_matches_oracle(dev, geom):
+    """ops.peak_search (spectrum + regional maxima + refinement on the device, peaks.hip) against the oracle's
+    literal alt_peak_search on the same phi: same maxima in the same (np.where) order, coordinates bit-exact,
+    heights to float64 rounding.  The product's host mirror must agree as well."""
     Nb, Nd, iters = geom
     y, b, s, _ = synth.make_batch(6, Nb, Nd, seed=23, snr_range=(10.0, 20.0))
     torch.manual_seed(2)
@@ -344,9 +367,78 @@ def test_device_peak_search_matches_host(dev, geom):
     pk, cnt = pk.cpu().numpy(), cnt.cpu().numpy()
     ph = phi.cpu().numpy()
     for i in range(ph.shape[0]):
-        host = peak_search.alt_peak_search({"phi": ph[i], "xbase": Nb, "ybase": Nd}, opts)
-        assert cnt[i] == host.shape[0] and cnt[i] > 0
+        want = PO.alt_peak_search_literal({"phi": ph[i].astype(np.complex128), "xbase": Nb, "ybase": Nd}, opts)
+        assert cnt[i] == want.shape[0] and cnt[i] > 0
         got = pk[i, :cnt[i]]
-        assert np.array_equal(got[:, :2], host[:, :2])
-        assert np.abs(got[:, 2] - host[:, 2]).max() <= 1e-9 * host[:, 2].max()
+        assert np.array_equal(got[:, :2], want[:, :2])
+        assert np.abs(got[:, 2] - want[:, 2]).max() <= 1e-9 * want[:, 2].max()
         assert not pk[i, cnt[i]:].any()
+        mirror = peak_search.alt_peak_search({"phi": ph[i], "xbase": Nb, "ybase": Nd}, opts)
+        assert np.array_equal(mirror[:, :2], want[:, :2])
+
+
+def test_regional_maxima_known_inputs_on_device(dev):
+    """The reference's own example image (peakSearchUtils.py:427-432: a 2 x 2 plateau of 5s in a 4 x 5 matrix; it
+    prints the mask, records none) plus plateau-rich random images, on the device path, against the flood fill."""
+    imgs = [np.array([[1, 2, 3, 2, 1], [2, 5, 5, 3, 2], [3, 5, 5, 4, 3], [2, 3, 4, 3, 2]], dtype=np.float64)]
+    want0 = np.zeros((4, 5), dtype=bool)
+    want0[1:3, 1:3] = True                                       # the plateau is the one regional maximum
+    rng = np.random.default_rng(3)
+    for levels in (2, 3, 5, 50):
+        imgs.append(rng.integers(0, levels, size=(4, 5)).astype(np.float64))
+    imgs.append(np.full((4, 5), 7.0))                             # constant image: no maximum
+    got = ops.regional_maxima(torch.from_numpy(np.stack(imgs)).to(dev)).cpu().numpy()
+    assert np.array_equal(got[0], want0)
+    for g, im in zip(got, imgs):
+        assert np.array_equal(g, PO.regional_maxima_floodfill(im))
+    big = rng.integers(0, 4, size=(3, 37, 41)).astype(np.float64)  # ragged sizes, many touching plateaus
+    gb = ops.regional_maxima(torch.from_numpy(big).to(dev)).cpu().numpy()
+    for g, im in zip(gb, big):
+        assert np.array_equal(g, PO.regional_maxima_floodfill(im))
+
+
+def test_delta_phi_known_input_on_device(dev):
+    """The reference's test_peak_searching input (peakSearchUtils.py:360-394): phi = e_2 of length 400 (20 x 20),
+    step 0.02, two refinement rounds.  |phi^H a|^2 = 1 at EVERY grid point, so which pixels are 'maxima' is decided
+    by rounding noise of the evaluation (a numerical tie everywhere; the reference prints whatever it gets and records
+    nothing): indices are not comparable between two evaluations.  What is checked: the device returns maxima, every
+    height is 1 to rounding and every refined position lies on the grid range, as for the oracle."""
+    phi = np.zeros(400, dtype=np.complex64)
+    phi[2] = 1.0
+    opts = {"xstep": 0.02, "ystep": 0.02, "iter": 2}
+    pk, cnt = ops.peak_search(torch.from_numpy(phi[None]).to(dev), 20, 20, opts, max_peaks=2048)
+    pk, cnt = pk.cpu().numpy()[0], int(cnt.cpu()[0])
+    want = PO.alt_peak_search_literal({"phi": phi.astype(np.complex128), "xbase": 20, "ybase": 20}, opts)
+    for rows in (pk[:min(cnt, 2048)], want):
+        assert rows.shape[0] > 0
+        assert np.abs(rows[:, 2] - 1.0).max() < 1e-12
+        assert rows[:, 0].min() >= 0.0 and rows[:, 0].max() <= 1.0 and np.abs(rows[:, 1]).max() <= 0.5
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_peaks_of_hip_phi_equal_peaks_of_reference_phi(dev, path):
+    """north_star: 'recovered peak indices bit-exact' end to end.  For every golden fixture the coarse regional-maxima
+    indices and the refined (tau, f) of the top-3 peaks computed from phi_HIP equal those computed (by the oracle's
+    literal peak search) from the REFERENCE's phi stored in the fixture."""
+    z, m, sd, (Nb, Nd, K, B, L, head, s2d) = load_case(path)
+    if Nb * Nd < 9:
+        pytest.skip("grid too small for a peak search")
+    y, b, s = torch.from_numpy(z["y"]), torch.from_numpy(z["b"]), torch.from_numpy(z["sigma"])
+    out = m(y.to(dev), b.to(dev), s.to(dev))
+    phi = out[3] if head else out
+    opts = {"xstep": 1 / (4 * Nd), "ystep": 1 / (4 * Nb), "iter": 2}
+    ax, ay = peak_search.coarse_axes(opts)
+    X, Y = np.meshgrid(ax, ay)
+    mask = ops.regional_maxima(ops.spectrum(phi, Nb, Nd, torch.from_numpy(ax), torch.from_numpy(ay))).cpu().numpy()
+    got = peak_search.batched_peak_search(phi, Nb, Nd, opts, top=3, max_peaks=1024)
+    for i in range(B):
+        ref_phi = z["phi"][i].astype(np.complex128)
+        Zr = PO.peak_search(ref_phi, X, Nb, Y, Nd)
+        want_mask = PO.regional_maxima_floodfill(Zr)
+        # a maximum whose margin over a neighbour is below the fp32 difference of the two phis is a numerical tie
+        # (none occurs on these fixtures; the assertion is exact)
+        assert np.array_equal(mask[i], want_mask)
+        want = _top(PO.alt_peak_search_literal({"phi": ref_phi, "xbase": Nb, "ybase": Nd}, opts))
+        # refined positions: same arg-max cell of the same np.arange grids
+        assert np.array_equal(got[i][:, :2], want[:, :2]), (got[i], want)
+        assert np.abs(got[i][:, 2] - want[:, 2]).max() <= 5e-4 * want[:, 2].max()

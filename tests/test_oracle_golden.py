@@ -9,16 +9,19 @@ import torch
 from oracle import admm_net_ref as R
 
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-CASES = [p for p in GOLD if "split" not in p]
+CASES = [p for p in GOLD if os.path.basename(p).startswith(("phiest_", "admmnet_"))]
 TOL_F32 = 2e-5      # oracle fp32 vs reference fp32: same formulas, different BLAS/LAPACK call order
 TOL_F64 = 5e-5      # reference fp32 vs ground truth fp64
 
 
-def load(p):
-    z = np.load(p)
-    meta = [int(v) for v in z["meta"]]
-    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
-    return z, sd, meta
+from golden_util import load_fixture as load   # weights stored, or rebuilt by seed and checksum-verified
+
+
+def test_depth_fixtures_present():
+    """Reference-made fixtures at the depth of the BASELINE configs (K = 8 on 8x16, K = 16 / 32 on 16x16)."""
+    names = {os.path.basename(p)[:-4] for p in CASES}
+    assert {"phiest_8x16_K8_perturbed", "phiest_16x16_K16_default", "phiest_16x16_K16_perturbed",
+            "phiest_16x16_K32_default"} <= names
 
 
 def test_fixture_inventory():
