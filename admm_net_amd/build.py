@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadmmnet_hip.so")
-SOURCES = ["api.hip", "prep.hip", "tridiag.hip", "tridiag_reg.hip", "tridiag_big.hip", "tql.hip", "rotapply.hip", "dc.hip", "rebuild.hip", "backrebuild.hip", "vgemm_big.hip", "arrow.hip",
+SOURCES = ["api.hip", "prep.hip", "tridiag.hip", "tridiag_reg.hip", "tridiag_big.hip", "tridiag_panel.hip", "tql.hip", "rotapply.hip", "dc.hip", "rebuild.hip", "backrebuild.hip", "vgemm_big.hip", "arrow.hip",
            "zstep.hip", "head.hip", "spectrum.hip", "peaks.hip"]
 HEADERS = ["common.h", "eig_core.h", "dc_core.h", "arrow_core.h", "rebuild_lds.h", os.path.join("..", "..", "include", "admmnet.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
@@ -21,7 +21,8 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # register shuffle per plane (7 VALU per rotation instead of 4)
 EXTRA_FLAGS = {"rotapply.hip": ["-fno-slp-vectorize"],
                # here the SLP pass re-packs the DPP reduction adds into v_mov_dpp + v_pk_add (3 instructions for 2)
-               "tridiag_reg.hip": ["-fno-slp-vectorize"]}
+               "tridiag_reg.hip": ["-fno-slp-vectorize"],
+               "tridiag_panel.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

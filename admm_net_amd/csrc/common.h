@@ -122,6 +122,8 @@ int launch_tridiag_reg(int D, int64_t nb, const Ws &ws, hipStream_t st, const fl
                        const float2 *phi = nullptr, const float *h = nullptr,
                        const float *lw = nullptr);   // tridiag_reg.hip, D <= 128
 int launch_tridiag_big(int D, int64_t nb, const Ws &ws, hipStream_t st);   // tridiag_big.hip, 128 < D <= 256
+bool tridiag_panel_supported(int D);                                      // tridiag_panel.hip, D == 256
+int launch_tridiag_panel(int D, int64_t nb, const Ws &ws, hipStream_t st);
 // tql.hip
 int launch_tql(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st);
 // rotapply.hip

@@ -15,6 +15,9 @@
 // also tried in the tridiagonalisation kernel below: its extra live vectors raised the spill
 // count from 57 to 178 VGPRs and made it 30 % slower, so that kernel keeps scalar FMAs.)  Same mathematics as tridiag_reg.hip (LAPACK chetd2 + cung2l,
 // first half of torch.linalg.eigh at /root/reference/admm_net.py:303).
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace admmnet {
@@ -396,14 +399,26 @@ __global__ __launch_bounds__(TB_THREADS) void ungtr_big_kernel(int D, const floa
         }
 }
 
+// D = 256: the panel-blocked kernel of tridiag_panel.hip (trailing updates on the matrix cores) produces the same
+// (d, e, reflector rows, taus); ADMMNET_TRIDIAG_BIG=sweep keeps the per-reflector register sweep below for A/B runs.
+static bool use_panel(int D) {
+    static const bool sweep = getenv("ADMMNET_TRIDIAG_BIG") && !strcmp(getenv("ADMMNET_TRIDIAG_BIG"), "sweep");
+    return !sweep && tridiag_panel_supported(D);
+}
+
 template <int NA>
 static int launch_tb(int D, int64_t nb, const Ws &ws, hipStream_t st) {
-    const size_t lds = sizeof(TbShared<NA>) + sizeof(float2) * (2 * NA - 1) * TB_THREADS;
-    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_big_kernel<NA>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(tridiag_big_kernel<NA>, dim3((unsigned)nb), dim3(TB_THREADS), lds, st, D, ws.Mbuf, ws.dT,
-                       ws.eT);
-    ADMM_HIP(hipGetLastError());
+    if (use_panel(D)) {
+        int rc = launch_tridiag_panel(D, nb, ws, st);
+        if (rc) return rc;
+    } else {
+        const size_t lds = sizeof(TbShared<NA>) + sizeof(float2) * (2 * NA - 1) * TB_THREADS;
+        ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_big_kernel<NA>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(tridiag_big_kernel<NA>, dim3((unsigned)nb), dim3(TB_THREADS), lds, st, D, ws.Mbuf, ws.dT,
+                           ws.eT);
+        ADMM_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(ungtr_big_kernel<NA>, dim3((unsigned)nb, (unsigned)((D + 127) / 128)), dim3(TB_THREADS), 0, st,
                        D, ws.Mbuf, ws.QV);
     ADMM_HIP(hipGetLastError());

@@ -1,0 +1,546 @@
+// tridiag_panel.hip -- K1 for D = 256 (BASELINE cfg 3/4/5, n = 257): panel-blocked Householder
+// tridiagonalisation with the trailing updates on the matrix cores.
+//
+// First half of torch.linalg.eigh at /root/reference/admm_net.py:303, LAPACK chetrd / clatrd (lower) organisation
+// (host model: tests/host_model/latrd_model.py):
+//   * panels of NB = 16 reflectors.  Inside a panel each reflector costs ONE Hermitian matrix-vector product with
+//     the panel-start matrix plus skinny corrections with the panel's (V, W) columns; the rank-2 updates of the
+//     trailing matrix -- half of all the flops -- are deferred to one rank-32 product per panel,
+//         M[16(p+1):, 16(p+1):] -= V W^H + W V^H,
+//     issued as v_mfma_f32_16x16x4_f32 straight into the resident tiles.
+//   * the Hermitian half of M lives in REGISTERS in the matrix cores' own accumulator layout: 136 lower-triangular
+//     16 x 16 tiles (diagonal tiles in full), tile (I, J) = 8 VGPRs of one wave (lane -> column l & 15, registers ->
+//     rows 4 (l >> 4) + q).  512 threads = 8 waves, wave w owns the block rows {w, 15 - w}: 17 tiles = 136 VGPRs.
+//     So the MFMA update needs no data movement at all, and the matrix-vector product reads every stored element
+//     once from registers for both triangle halves:
+//         y_I += T_IJ v_J      (row form: per-lane products, ONE 16-lane DPP reduction per block row)
+//         y_J += T_IJ^H v_I    (column form: per-lane sums over the 4 rows a lane holds + a 4-group reduction)
+//   * V, W panels (2 x 36 KB), the column / reflector vectors and the partial sums live in LDS.
+// Five barriers per reflector (column -> norm -> reflector -> matrix-vector product -> dot) instead of the rank-2
+// update's register sweep per reflector of tridiag_big.hip; outputs (d, e, reflector rows, taus) in that kernel's
+// format, so ungtr_big_kernel / the D&C / the back-transform are unchanged consumers.
+//
+// Index conventions (arrow-first order, as every tridiagonalisation here): F = [[corner, a^H], [a, M]], M is D x D.
+// Reflector u (0 <= u < D) has its unit position at M-row u, annihilates F column u below it (for u >= 1 that is
+// column c = u - 1 of M, for u = 0 the arrow a), d[u] = F[u][u], e[u] = beta_u.  The prologue reflector u = 0 is
+// handled as column 15 of a virtual panel -1 whose other columns are zero.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace admmnet {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int PN_D = 256;
+constexpr int PN_THREADS = 512;
+constexpr int PN_NT = 16;          // tiles per dimension
+constexpr int PN_PITCH = 18;       // float2 per panel row: 16 columns + 2 pad (144 B rows: 16-byte aligned, spread over banks)
+
+struct PnShared {
+    float2 Vp[PN_D][PN_PITCH];     // panel reflectors (unnormalised), row r = M-row
+    float2 Wp[PN_D][PN_PITCH];     // panel w vectors
+    float2 Ap[PN_D][PN_PITCH];     // block column p of the panel-start matrix (the 16 columns the panel reduces)
+    float2 colbuf[PN_D];           // the arrow: column of the prologue reflector
+    float2 vbuf[PN_D];             // current reflector (zero above its unit position)
+    float2 yrow[PN_D];             // row-form part of M v (written by the owner wave of each block row)
+    float2 ycol[8][PN_D];          // column-form partials per wave
+    float2 g[32];                  // g[jj] = W_jj^H v, g[16 + jj] = V_jj^H v
+    float2 red2[8];
+    float2 pu;                     // p[u] of the current reflector
+    float red[8];
+    float2 alpha;
+};
+
+// sum over the 16 lanes of a DPP row (every lane gets the sum)
+__device__ __forceinline__ float pn_row16_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xF, 0xF, false));
+    return x;
+}
+// sum over the four 16-lane rows of the wave, lane by lane (x of lanes l, l ^ 16, l ^ 32, l ^ 48): every lane gets it
+__device__ __forceinline__ float pn_group_sum(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    x = a + b;
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// x + (x of the neighbouring lane l ^ 1): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float pn_pair_sum(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float pn_wave_sum(float x) { return pn_group_sum(pn_row16_sum(x)); }
+
+__device__ __forceinline__ float2 pn_fma_c(float2 acc, float2 a, float2 b) {      // acc + a b
+    acc.x = fmaf(a.x, b.x, fmaf(-a.y, b.y, acc.x));
+    acc.y = fmaf(a.x, b.y, fmaf(a.y, b.x, acc.y));
+    return acc;
+}
+__device__ __forceinline__ float2 pn_fms_cc(float2 acc, float2 a, float2 b) {    // acc - a conj(b)
+    acc.x = fmaf(-a.x, b.x, fmaf(-a.y, b.y, acc.x));
+    acc.y = fmaf(a.x, b.y, fmaf(-a.y, b.x, acc.y));
+    return acc;
+}
+__device__ __forceinline__ float2 pn_fms_c(float2 acc, float2 a, float2 b) {     // acc - a b
+    acc.x = fmaf(-a.x, b.x, fmaf(a.y, b.y, acc.x));
+    acc.y = fmaf(-a.x, b.y, fmaf(-a.y, b.x, acc.y));
+    return acc;
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pn_lo(f32x4 a) { return v2f{a.x, a.y}; }
+__device__ __forceinline__ v2f pn_hi(f32x4 a) { return v2f{a.z, a.w}; }
+// one 16 x 16 tile (tre, tim: rows 4 g + q of column c16) in the matrix-vector product, packed FMAs over row pairs:
+//   ROW form   P[q] += T[q][c] vJ[c]            (Pr, Pi: rows 01 | 23; the caller passes vJ = 0 for a diagonal tile,
+//                                                 whose product is taken by the column form alone)
+//   COL form   C    += sum_q conj(T[q][c]) vI[q]  (vIr, vIi: the four row entries of v, planar pairs; Cr, Ci pairs)
+__device__ __forceinline__ void pn_tile_mv(f32x4 tre, f32x4 tim, float2 vJ, v2f vIr01, v2f vIr23, v2f vIi01,
+                                           v2f vIi23, v2f &Pr01, v2f &Pr23, v2f &Pi01, v2f &Pi23, v2f &Cr, v2f &Ci) {
+    const v2f r01 = pn_lo(tre), r23 = pn_hi(tre), i01 = pn_lo(tim), i23 = pn_hi(tim);
+    const v2f jx = v2f{vJ.x, vJ.x}, jy = v2f{vJ.y, vJ.y};
+    Pr01 = __builtin_elementwise_fma(r01, jx, Pr01);
+    Pi01 = __builtin_elementwise_fma(r01, jy, Pi01);
+    Pr23 = __builtin_elementwise_fma(r23, jx, Pr23);
+    Pi23 = __builtin_elementwise_fma(r23, jy, Pi23);
+    Pr01 = __builtin_elementwise_fma(-i01, jy, Pr01);
+    Pi01 = __builtin_elementwise_fma(i01, jx, Pi01);
+    Pr23 = __builtin_elementwise_fma(-i23, jy, Pr23);
+    Pi23 = __builtin_elementwise_fma(i23, jx, Pi23);
+    // conj(T) v = (Tr vr + Ti vi) + i (Tr vi - Ti vr)
+    Cr = __builtin_elementwise_fma(r01, vIr01, Cr);
+    Ci = __builtin_elementwise_fma(r01, vIi01, Ci);
+    Cr = __builtin_elementwise_fma(i01, vIi01, Cr);
+    Ci = __builtin_elementwise_fma(-i01, vIr01, Ci);
+    Cr = __builtin_elementwise_fma(r23, vIr23, Cr);
+    Ci = __builtin_elementwise_fma(r23, vIi23, Ci);
+    Cr = __builtin_elementwise_fma(i23, vIi23, Cr);
+    Ci = __builtin_elementwise_fma(-i23, vIr23, Ci);
+}
+
+// Four per-lane partial vectors (one per block column, each to be summed over the four 16-lane rows of the wave)
+// reduced together: 3 swaps + 3 adds instead of 8 + 8.  Result: row 0 holds the total of x0, row 1 of x2, row 2 of x1,
+// row 3 of x3 (v_permlane32_swap: upper half of the first operand <-> lower half of the second; v_permlane16_swap: odd
+// rows of the first <-> even rows of the second).
+__device__ __forceinline__ float pn_quad_group_sum(float x0, float x1, float x2, float x3) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x2), "+v"(x3));
+    float a = x0 + x1, b = x2 + x3;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+// slot s of wave w: tile (IB, s) for s <= IB, tile (IA, 16 - s) otherwise   (IA = w, IB = 15 - w)
+#define PN_SLOT_IJ(s, I, J)            \
+    int I, J;                          \
+    if ((s) <= IB) { I = IB; J = (s); } \
+    else { I = IA; J = 16 - (s); }
+
+template <bool TIMING>
+__global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__restrict__ Mbuf, float *__restrict__ dT,
+                                                                      float *__restrict__ eT,
+                                                                      unsigned long long *__restrict__ tdbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PnShared &sh = *reinterpret_cast<PnShared *>(smem);
+    constexpr int D = PN_D, n = D + 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile ownership tests below are uniform branches
+    const int c16_0 = lane & 15, g_0 = lane >> 4;
+    int c16 = c16_0, g = g_0;
+    int IA = wave, IB = 15 - wave;
+    const int64_t bm = blockIdx.x;
+    float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
+    float *dcol = dT + bm * n, *ecol = eT + bm * n;
+
+    // ---- load the Hermitian half into the accumulator layout
+    f32x4 tr[17], ti[17];
+#pragma unroll
+    for (int s = 0; s < 17; ++s) {
+        PN_SLOT_IJ(s, I, J)
+        const float2 *src = Mg + (int64_t)(16 * I + 4 * g) * D + 16 * J + c16;
+        const float2 e0 = src[0], e1 = src[D], e2 = src[2 * D], e3 = src[3 * D];
+        tr[s] = f32x4{e0.x, e1.x, e2.x, e3.x};
+        ti[s] = f32x4{e0.y, e1.y, e2.y, e3.y};
+    }
+    const float corner = Mg[(int64_t)D * D + D].x;
+    for (int i = tid; i < D * PN_PITCH; i += PN_THREADS) {
+        (&sh.Vp[0][0])[i] = make_float2(0.f, 0.f);
+        (&sh.Wp[0][0])[i] = make_float2(0.f, 0.f);
+    }
+    if (tid < D) sh.colbuf[tid] = Mg[(int64_t)D * D + tid];   // the arrow: column of the prologue reflector
+    // (no barrier yet: the first one of the step loop orders these stores before any reader, and every global
+    //  store below comes after at least one barrier, i.e. after every wave's matrix loads have been issued AND
+    //  their results consumed into registers by the slot loop above)
+    __syncthreads();
+
+    const int r = tid >> 1, half = tid & 1;   // two adjacent lanes per row: each takes half of the panel columns in the
+                                              // skinny corrections, DPP pair sums join them (wave w: rows 32 w .. 32 w + 31)
+    // carried from one reflector to the next (same panel): its v and w entries of this thread's row, and -- known to
+    // every thread -- the two entries at its unit row, (hu, wu) = (v, w)[u].  With them the next column is brought up to
+    // date without waiting for the panel stores of the previous step (no barrier between the steps).
+    float2 xcol = make_float2(0.f, 0.f), vreg = make_float2(0.f, 0.f), wreg = make_float2(0.f, 0.f),
+           preg = make_float2(0.f, 0.f), hu = make_float2(0.f, 0.f), wu = make_float2(0.f, 0.f);
+    unsigned long long tmark = TIMING ? __builtin_amdgcn_s_memtime() : 0ull, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto mark = [&](int id) {
+        if constexpr (TIMING) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            tacc[id] += t - tmark;
+            tmark = t;
+        }
+    };
+
+    for (int p = -1; p < PN_NT; ++p) {
+        for (int j = (p < 0) ? 15 : 0; j < 16; ++j) {
+            const int c = 16 * p + j, u = c + 1;
+            // the lane coordinates are re-derived per step from an opaque copy: otherwise every LDS address of the
+            // unrolled tile loops below is hoisted out of the reflector loop and kept alive (~90 VGPRs, spills)
+            c16 = c16_0;
+            g = g_0;
+            asm volatile("" : "+v"(c16), "+v"(g));
+            {   // the same for the wave's block rows: the ownership tests are re-derived (scalar compares) per step
+                int wv = wave;   // instead of ~100 precomputed conditions parked in spill lanes
+                asm volatile("" : "+s"(wv));
+                IA = wv;
+                IB = 15 - wv;
+            }
+            // ---- B: bring the column up to date with the panel's earlier reflectors; d, alpha, |x|^2
+            {
+                float2 x = (p >= 0) ? sh.Ap[r][j] : sh.colbuf[r];
+                if (p >= 0 && j > 0) {                             // (uniform)
+                    float2 acc = make_float2(0.f, 0.f);
+                    for (int j0 = 4 * half; j0 < j - 1; j0 += 8) {   // this lane: columns j0 .. j0 + 3 of every eight
+                        float2 vr[4], wr[4], vc[4], wc[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            vr[q] = sh.Vp[r][j0 + q];
+                            wr[q] = sh.Wp[r][j0 + q];
+                            vc[q] = sh.Vp[c][j0 + q];
+                            wc[q] = sh.Wp[c][j0 + q];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (j0 + q < j - 1) {
+                                acc = pn_fms_cc(acc, vr[q], wc[q]);
+                                acc = pn_fms_cc(acc, wr[q], vc[q]);
+                            }
+                        }
+                    }
+                    x.x += pn_pair_sum(acc.x);
+                    x.y += pn_pair_sum(acc.y);
+                    x = pn_fms_cc(x, vreg, wu);      // column j - 1 from registers: (V, W)[c][j - 1] = (hu, wu)
+                    x = pn_fms_cc(x, wreg, hu);
+                }
+                xcol = x;
+                if (half == 0) {
+                    if (r == c) dcol[u] = x.x;
+                    if (p < 0 && r == 0) dcol[0] = corner;
+                    if (r == u) sh.alpha = x;
+                }
+                float pn = (half == 0 && r > u) ? (x.x * x.x + x.y * x.y) : 0.f;
+                pn = pn_wave_sum(pn);
+                if (lane == 0) sh.red[wave] = pn;
+            }
+            if (u >= D) break;         // c = D - 1: only d[D] was due (uniform)
+            mark(0);
+            __syncthreads();   // (B2)
+            // ---- C: the reflector
+            const float xn2 = ((sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3])) + ((sh.red[4] + sh.red[5]) + (sh.red[6] + sh.red[7]));
+            const float2 alpha = sh.alpha;
+            float beta, tre, tim, sr, si;
+            householder_c(alpha.x, alpha.y, xn2, beta, tre, tim, sr, si);
+            const float g2 = sr * sr + si * si;
+            const float2 tau = make_float2(tre * g2, tim * g2);   // unnormalised reflector: H = I - tau v v^H, v = (alpha - beta, x)
+            hu = make_float2(alpha.x - beta, alpha.y);
+            vreg = (r == u) ? hu : (r > u ? xcol : make_float2(0.f, 0.f));
+            if (half == 0) {
+                sh.vbuf[r] = vreg;
+                Mg[(int64_t)u * D + r] = vreg;                    // reflector row u for the Q kernel
+            }
+            if (tid == 0) {
+                ecol[u] = beta;
+                Mg[(int64_t)D * D + u] = tau;                      // taus live in the consumed arrow slot
+            }
+            if (tre == 0.f && tim == 0.f) {                       // H = I (uniform): v = 0, w = 0
+                hu = make_float2(0.f, 0.f);
+                wu = make_float2(0.f, 0.f);
+                wreg = make_float2(0.f, 0.f);
+                if (half == 0) {
+                    sh.Vp[r][j] = make_float2(0.f, 0.f);
+                    sh.Wp[r][j] = make_float2(0.f, 0.f);
+                }
+                continue;
+            }
+            mark(1);
+            __syncthreads();   // (B3)
+            // ---- D: y = M v with the resident half (+ the panel dots W^H v, V^H v)
+            {
+                const int J0 = u >> 4;
+                v2f Ar01, Ar23, Ai01, Ai23, Br01, Br23, Bi01, Bi23;   // v at the rows of block rows IA / IB (planar pairs)
+                {
+                    const float2 *va = &sh.vbuf[16 * IA + 4 * g], *vb = &sh.vbuf[16 * IB + 4 * g];
+                    const float2 a0 = va[0], a1 = va[1], a2 = va[2], a3 = va[3];
+                    const float2 b0 = vb[0], b1 = vb[1], b2 = vb[2], b3 = vb[3];
+                    Ar01 = v2f{a0.x, a1.x}; Ar23 = v2f{a2.x, a3.x}; Ai01 = v2f{a0.y, a1.y}; Ai23 = v2f{a2.y, a3.y};
+                    Br01 = v2f{b0.x, b1.x}; Br23 = v2f{b2.x, b3.x}; Bi01 = v2f{b0.y, b1.y}; Bi23 = v2f{b2.y, b3.y};
+                }
+                const v2f z2 = v2f{0.f, 0.f};
+                v2f PAr01 = z2, PAr23 = z2, PAi01 = z2, PAi23 = z2, PBr01 = z2, PBr23 = z2, PBi01 = z2, PBi23 = z2;
+#pragma unroll
+                for (int JQ = 0; JQ < PN_NT; JQ += 4) {
+                    if (JQ + 3 >= J0 && JQ <= IB) {   // (uniform) four block columns per pass: one joint lane reduction
+                        float cx[4], cy[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int J = JQ + k;
+                            v2f Cr = z2, Ci = z2;
+                            if (J >= J0 && J <= IB) {   // (uniform)
+                                const float2 vJ = sh.vbuf[16 * J + c16];
+                                const float mB = (J == IB) ? 0.f : 1.f, mA = (J == IA) ? 0.f : 1.f;
+                                pn_tile_mv(tr[J], ti[J], make_float2(vJ.x * mB, vJ.y * mB), Br01, Br23, Bi01, Bi23, PBr01,
+                                           PBr23, PBi01, PBi23, Cr, Ci);
+                                if (J <= IA)
+                                    pn_tile_mv(tr[16 - J], ti[16 - J], make_float2(vJ.x * mA, vJ.y * mA), Ar01, Ar23, Ai01,
+                                               Ai23, PAr01, PAr23, PAi01, PAi23, Cr, Ci);
+                            }
+                            cx[k] = Cr.x + Cr.y;
+                            cy[k] = Ci.x + Ci.y;
+                        }
+                        const float tx = pn_quad_group_sum(cx[0], cx[1], cx[2], cx[3]);
+                        const float ty = pn_quad_group_sum(cy[0], cy[1], cy[2], cy[3]);
+                        const int Jl = JQ + ((g & 1) << 1) + (g >> 1);   // lane row g holds block column JQ + {0, 2, 1, 3}[g]
+                        if (Jl >= J0 && Jl <= IB) sh.ycol[wave][16 * Jl + c16] = make_float2(tx, ty);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep each pass's loads inside it (VGPR budget)
+                }
+                mark(2);
+                if (IB >= J0) {
+                    float2 P[4] = {make_float2(PBr01.x, PBi01.x), make_float2(PBr01.y, PBi01.y),
+                                   make_float2(PBr23.x, PBi23.x), make_float2(PBr23.y, PBi23.y)};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        P[q].x = pn_row16_sum(P[q].x);
+                        P[q].y = pn_row16_sum(P[q].y);
+                    }
+                    if (c16 == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) sh.yrow[16 * IB + 4 * g + q] = P[q];
+                    }
+                }
+                if (IA >= J0) {
+                    float2 P[4] = {make_float2(PAr01.x, PAi01.x), make_float2(PAr01.y, PAi01.y),
+                                   make_float2(PAr23.x, PAi23.x), make_float2(PAr23.y, PAi23.y)};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        P[q].x = pn_row16_sum(P[q].x);
+                        P[q].y = pn_row16_sum(P[q].y);
+                    }
+                    if (c16 == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) sh.yrow[16 * IA + 4 * g + q] = P[q];
+                    }
+                }
+                mark(3);
+                // panel dots: dot id q = 4 wave + g : q < 16 -> W_q^H v, else V_{q-16}^H v; the 16 lanes of a group
+                // stride the rows (v is zero above its unit row, so all sixteen 16-row blocks are summed: fixed trip
+                // count, all loads in flight together)
+                if (p >= 0 && j > 0) {
+                    const int q = 4 * wave + g, jj = q & 15;
+                    float2 acc = make_float2(0.f, 0.f), acc2 = make_float2(0.f, 0.f);
+                    const float2(*X)[PN_PITCH] = (q < 16) ? sh.Wp : sh.Vp;
+#pragma unroll
+                    for (int i = 0; i < PN_NT; i += 2) {
+                        acc = cmacc(acc, X[16 * i + c16][jj], sh.vbuf[16 * i + c16]);
+                        acc2 = cmacc(acc2, X[16 * i + 16 + c16][jj], sh.vbuf[16 * i + 16 + c16]);
+                    }
+                    acc.x = pn_row16_sum(acc.x + acc2.x);
+                    acc.y = pn_row16_sum(acc.y + acc2.y);
+                    if (c16 == 0 && jj < j) sh.g[q] = acc;
+                }
+            }
+            mark(4);
+            __syncthreads();   // (B4)
+            // ---- E: assemble y, corrections, p = tau y, p^H v   (lane pair per row: partial sums / columns split)
+            {
+                float2 y = make_float2(0.f, 0.f);
+                {
+                    const int J = r >> 4;
+                    const int wmax = min(7, 15 - J);
+                    float2 t[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) t[w] = sh.ycol[4 * half + w][r];   // (slots above wmax: stale finite values)
+                    if (half == 0) y = sh.yrow[r];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        if (4 * half + w <= wmax) {
+                            y.x += t[w].x;
+                            y.y += t[w].y;
+                        }
+                    }
+                    if (p >= 0) {
+                        for (int j0 = 4 * half; j0 < j; j0 += 8) {
+                            float2 vr[4], wr[4], g1[4], g2[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                vr[q] = sh.Vp[r][j0 + q];
+                                wr[q] = sh.Wp[r][j0 + q];
+                                g1[q] = sh.g[j0 + q];
+                                g2[q] = sh.g[16 + j0 + q];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (j0 + q < j) {
+                                    y = pn_fms_c(y, vr[q], g1[q]);
+                                    y = pn_fms_c(y, wr[q], g2[q]);
+                                }
+                            }
+                        }
+                    }
+                    y.x = pn_pair_sum(y.x);
+                    y.y = pn_pair_sum(y.y);
+                    y = (r >= u) ? cmul(tau, y) : make_float2(0.f, 0.f);
+                }
+                preg = y;
+                if (half == 0 && r == u) sh.pu = y;
+                float2 dp = cmacc(make_float2(0.f, 0.f), y, vreg);   // conj(p) v
+                if (half) dp = make_float2(0.f, 0.f);
+                dp.x = pn_wave_sum(dp.x);
+                dp.y = pn_wave_sum(dp.y);
+                if (lane == 0) sh.red2[wave] = dp;
+            }
+            mark(5);
+            __syncthreads();   // (B5)
+            // ---- F: w = p - (tau / 2)(p^H v) v ; store the panel column (read again only behind later barriers)
+            {
+                float2 dot = sh.red2[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) {
+                    dot.x += sh.red2[q].x;
+                    dot.y += sh.red2[q].y;
+                }
+                float2 al = cmul(tau, dot);
+                al.x *= -0.5f;
+                al.y *= -0.5f;
+                wu = pn_fma_c(sh.pu, al, hu);
+                wreg = (r >= u) ? pn_fma_c(preg, al, vreg) : make_float2(0.f, 0.f);
+                if (half == 0) {
+                    sh.Vp[r][j] = vreg;
+                    sh.Wp[r][j] = wreg;
+                }
+            }
+            mark(6);
+        }
+        if (p == PN_NT - 1) break;
+        __syncthreads();
+        // ---- trailing update on the matrix cores: tiles (I, J), I >= J >= p + 1:  T -= V_I W_J^H + W_I V_J^H
+        //      re -= Vr Wr' + Vi Wi' + Wr Vr' + Wi Vi' ;  im -= Vi Wr' - Vr Wi' + Wi Vr' - Wr Vi'   (' = block column J)
+        //      The A operands (rows of block row I; lane (m = c16, g) supplies k' = 4 g + s at step s) carry the signs,
+        //      so the B operands go from LDS to the matrix cores untouched.  One block row at a time: 24 operand
+        //      registers live across the column loop.
+        c16 = c16_0;
+        g = g_0;
+        asm volatile("" : "+v"(c16), "+v"(g));
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int P1 = p + 1;
+            const int I = half ? IA : IB;
+            // (compiler-level memory barrier: without it the second block row's B-operand loads are merged with the
+            //  first one's -- same LDS addresses -- and all sixteen block columns' operands stay live: 85 VGPR spills)
+            asm volatile("" ::: "memory");
+            if (I < P1) continue;   // (uniform)
+            float nVr[4], nVi[4], pVr[4], nWr[4], nWi[4], pWr[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float2 v = sh.Vp[16 * I + c16][4 * g + s], w = sh.Wp[16 * I + c16][4 * g + s];
+                nVr[s] = -v.x; nVi[s] = -v.y; pVr[s] = v.x;
+                nWr[s] = -w.x; nWi[s] = -w.y; pWr[s] = w.x;
+            }
+#pragma unroll
+            for (int J = 0; J < PN_NT; ++J) {
+                if (J >= P1 && J <= I) {   // (uniform)
+                    float2 bV[4], bW[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        bV[s] = sh.Vp[16 * J + c16][4 * g + s];
+                        bW[s] = sh.Wp[16 * J + c16][4 * g + s];
+                    }
+                    f32x4 re = half ? tr[16 - J] : tr[J], im = half ? ti[16 - J] : ti[J];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        re = __builtin_amdgcn_mfma_f32_16x16x4f32(nVr[s], bW[s].x, re, 0, 0, 0);
+                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(nVi[s], bW[s].x, im, 0, 0, 0);
+                        re = __builtin_amdgcn_mfma_f32_16x16x4f32(nVi[s], bW[s].y, re, 0, 0, 0);
+                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(pVr[s], bW[s].y, im, 0, 0, 0);
+                        re = __builtin_amdgcn_mfma_f32_16x16x4f32(nWr[s], bV[s].x, re, 0, 0, 0);
+                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(nWi[s], bV[s].x, im, 0, 0, 0);
+                        re = __builtin_amdgcn_mfma_f32_16x16x4f32(nWi[s], bV[s].y, re, 0, 0, 0);
+                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(pWr[s], bV[s].y, im, 0, 0, 0);
+                    }
+                    if (half) {
+                        tr[16 - J] = re;
+                        ti[16 - J] = im;
+                    } else {
+                        tr[J] = re;
+                        ti[J] = im;
+                    }
+                    if (J == P1) {   // (uniform) the next panel's columns, up to date: rows 16 I + 4 g + q, column c16
+                        float2 *dst = &sh.Ap[16 * I + 4 * g][c16];
+                        dst[0] = make_float2(re.x, im.x);
+                        dst[PN_PITCH] = make_float2(re.y, im.y);
+                        dst[2 * PN_PITCH] = make_float2(re.z, im.z);
+                        dst[3 * PN_PITCH] = make_float2(re.w, im.w);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // operands of block column J + 1 are not hoisted above these MFMAs
+            }
+        }
+        mark(7);
+        __syncthreads();   // the next panel's columns (Ap) are complete; Vp / Wp may be rewritten
+    }
+    if constexpr (TIMING) {
+        if (tid == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(&tdbg[i], tacc[i]);
+    }
+    if (tid == 0) ecol[D] = 0.f;
+}
+
+bool tridiag_panel_supported(int D) { return D == PN_D; }
+
+int launch_tridiag_panel(int D, int64_t nb, const Ws &ws, hipStream_t st) {
+    if (!tridiag_panel_supported(D)) {
+        set_error("tridiag_panel: D=%d unsupported (256 only)", D);
+        return ADMMNET_E_ARG;
+    }
+    const size_t lds = sizeof(PnShared);
+    static const bool timing = getenv("ADMMNET_PN_TIMING") != nullptr;   // developer aid, never on by default
+    if (timing) {
+        unsigned long long *ptime = nullptr, hb[8];
+        ADMM_HIP(hipMalloc(&ptime, sizeof(hb)));
+        ADMM_HIP(hipMemsetAsync(ptime, 0, sizeof(hb), st));
+        ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_panel_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(tridiag_panel_kernel<true>, dim3((unsigned)nb), dim3(PN_THREADS), lds, st, ws.Mbuf, ws.dT,
+                           ws.eT, ptime);
+        ADMM_HIP(hipGetLastError());
+        ADMM_HIP(hipMemcpyAsync(hb, ptime, sizeof(hb), hipMemcpyDeviceToHost, st));
+        ADMM_HIP(hipStreamSynchronize(st));
+        ADMM_HIP(hipFree(ptime));
+        static const char *nm[8] = {"column+norm", "reflector", "matvec tiles", "row flush", "panel dots", "assemble+dot", "w+store", "mfma update"};
+        fprintf(stderr, "[tridiag_panel timing] nb=%lld  mean cycles per matrix (wave 0, barrier waits fall into the NEXT phase):\n",
+                (long long)nb);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, "   %-14s %10.0f\n", nm[i], (double)hb[i] / (double)nb);
+        return ADMMNET_OK;
+    }
+    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_panel_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(tridiag_panel_kernel<false>, dim3((unsigned)nb), dim3(PN_THREADS), lds, st, ws.Mbuf, ws.dT, ws.eT,
+                       (unsigned long long *)nullptr);
+    ADMM_HIP(hipGetLastError());
+    return ADMMNET_OK;
+}
+
+}  // namespace admmnet
