@@ -49,6 +49,9 @@ struct PnShared {
     float2 g[32];                  // g[jj] = W_jj^H v, g[16 + jj] = V_jj^H v
     float2 red2[8];
     float2 pu;                     // p[u] of the current reflector
+    int skip;                      // the current reflector is the identity
+    float dbuf[PN_D + 4], ebuf[PN_D + 4];   // d, e and the taus are gathered here and written out once: a global store on
+    float2 taubuf[PN_D];                    // the per-reflector path makes the next barrier wait for its completion
     float red[8];
     float2 alpha;
 };
@@ -178,8 +181,8 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
     //  their results consumed into registers by the slot loop above)
     __syncthreads();
 
-    const int r = tid >> 1, half = tid & 1;   // two adjacent lanes per row: each takes half of the panel columns in the
-                                              // skinny corrections, DPP pair sums join them (wave w: rows 32 w .. 32 w + 31)
+    const int r = tid;                 // row owned by the threads of waves 0..3 (one wave per SIMD; splitting the rows
+                                       // over lane pairs of all eight waves was measured slower: same instruction total)
     // carried from one reflector to the next (same panel): its v and w entries of this thread's row, and -- known to
     // every thread -- the two entries at its unit row, (hu, wu) = (v, w)[u].  With them the next column is brought up to
     // date without waiting for the panel stores of the previous step (no barrier between the steps).
@@ -209,11 +212,10 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 IB = 15 - wv;
             }
             // ---- B: bring the column up to date with the panel's earlier reflectors; d, alpha, |x|^2
-            {
+            if (tid < D) {
                 float2 x = (p >= 0) ? sh.Ap[r][j] : sh.colbuf[r];
-                if (p >= 0 && j > 0) {                             // (uniform)
-                    float2 acc = make_float2(0.f, 0.f);
-                    for (int j0 = 4 * half; j0 < j - 1; j0 += 8) {   // this lane: columns j0 .. j0 + 3 of every eight
+                if (r >= c && p >= 0 && j > 0) {
+                    for (int j0 = 0; j0 < j - 1; j0 += 4) {   // four columns per pass: all 16 loads in flight together
                         float2 vr[4], wr[4], vc[4], wc[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -225,58 +227,55 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             if (j0 + q < j - 1) {
-                                acc = pn_fms_cc(acc, vr[q], wc[q]);
-                                acc = pn_fms_cc(acc, wr[q], vc[q]);
+                                x = pn_fms_cc(x, vr[q], wc[q]);
+                                x = pn_fms_cc(x, wr[q], vc[q]);
                             }
                         }
                     }
-                    x.x += pn_pair_sum(acc.x);
-                    x.y += pn_pair_sum(acc.y);
                     x = pn_fms_cc(x, vreg, wu);      // column j - 1 from registers: (V, W)[c][j - 1] = (hu, wu)
                     x = pn_fms_cc(x, wreg, hu);
                 }
                 xcol = x;
-                if (half == 0) {
-                    if (r == c) dcol[u] = x.x;
-                    if (p < 0 && r == 0) dcol[0] = corner;
-                    if (r == u) sh.alpha = x;
-                }
-                float pn = (half == 0 && r > u) ? (x.x * x.x + x.y * x.y) : 0.f;
+                if (r == c) sh.dbuf[u] = x.x;
+                if (p < 0 && r == 0) sh.dbuf[0] = corner;
+                if (r == u) sh.alpha = x;
+                float pn = (r > u) ? (x.x * x.x + x.y * x.y) : 0.f;
                 pn = pn_wave_sum(pn);
                 if (lane == 0) sh.red[wave] = pn;
             }
             if (u >= D) break;         // c = D - 1: only d[D] was due (uniform)
             mark(0);
             __syncthreads();   // (B2)
-            // ---- C: the reflector
-            const float xn2 = ((sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3])) + ((sh.red[4] + sh.red[5]) + (sh.red[6] + sh.red[7]));
-            const float2 alpha = sh.alpha;
-            float beta, tre, tim, sr, si;
-            householder_c(alpha.x, alpha.y, xn2, beta, tre, tim, sr, si);
-            const float g2 = sr * sr + si * si;
-            const float2 tau = make_float2(tre * g2, tim * g2);   // unnormalised reflector: H = I - tau v v^H, v = (alpha - beta, x)
-            hu = make_float2(alpha.x - beta, alpha.y);
-            vreg = (r == u) ? hu : (r > u ? xcol : make_float2(0.f, 0.f));
-            if (half == 0) {
+            // ---- C: the reflector (scalars on the row waves only: the other four need no tau, just the H = I flag)
+            float2 tau = make_float2(0.f, 0.f);
+            if (wave < 4) {   // (uniform)
+                const float xn2 = (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
+                const float2 alpha = sh.alpha;
+                float beta, tre, tim, sr, si;
+                householder_c(alpha.x, alpha.y, xn2, beta, tre, tim, sr, si);
+                const float g2 = sr * sr + si * si;
+                tau = make_float2(tre * g2, tim * g2);   // unnormalised reflector: H = I - tau v v^H, v = (alpha - beta, x)
+                hu = make_float2(alpha.x - beta, alpha.y);
+                vreg = (r == u) ? hu : (r > u ? xcol : make_float2(0.f, 0.f));
                 sh.vbuf[r] = vreg;
-                Mg[(int64_t)u * D + r] = vreg;                    // reflector row u for the Q kernel
+                if (tid == 0) {
+                    sh.ebuf[u] = beta;
+                    sh.taubuf[u] = tau;
+                    sh.skip = (tre == 0.f && tim == 0.f) ? 1 : 0;
+                }
             }
-            if (tid == 0) {
-                ecol[u] = beta;
-                Mg[(int64_t)D * D + u] = tau;                      // taus live in the consumed arrow slot
-            }
-            if (tre == 0.f && tim == 0.f) {                       // H = I (uniform): v = 0, w = 0
+            mark(1);
+            __syncthreads();   // (B3)
+            if (__builtin_amdgcn_readfirstlane(sh.skip)) {        // H = I (uniform): v = 0, w = 0
                 hu = make_float2(0.f, 0.f);
                 wu = make_float2(0.f, 0.f);
                 wreg = make_float2(0.f, 0.f);
-                if (half == 0) {
+                if (tid < D) {
                     sh.Vp[r][j] = make_float2(0.f, 0.f);
                     sh.Wp[r][j] = make_float2(0.f, 0.f);
                 }
                 continue;
             }
-            mark(1);
-            __syncthreads();   // (B3)
             // ---- D: y = M v with the resident half (+ the panel dots W^H v, V^H v)
             {
                 const int J0 = u >> 4;
@@ -348,7 +347,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 // panel dots: dot id q = 4 wave + g : q < 16 -> W_q^H v, else V_{q-16}^H v; the 16 lanes of a group
                 // stride the rows (v is zero above its unit row, so all sixteen 16-row blocks are summed: fixed trip
                 // count, all loads in flight together)
-                if (p >= 0 && j > 0) {
+                if (p >= 0 && 4 * (wave & 3) < j) {   // (uniform) at least one of this wave's four columns exists
                     const int q = 4 * wave + g, jj = q & 15;
                     float2 acc = make_float2(0.f, 0.f), acc2 = make_float2(0.f, 0.f);
                     const float2(*X)[PN_PITCH] = (q < 16) ? sh.Wp : sh.Vp;
@@ -364,25 +363,25 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
             }
             mark(4);
             __syncthreads();   // (B4)
-            // ---- E: assemble y, corrections, p = tau y, p^H v   (lane pair per row: partial sums / columns split)
-            {
+            // ---- E: assemble y, corrections, p = tau y, p^H v
+            if (tid < D) {
                 float2 y = make_float2(0.f, 0.f);
-                {
+                if (r >= u) {
                     const int J = r >> 4;
+                    y = sh.yrow[r];
                     const int wmax = min(7, 15 - J);
-                    float2 t[4];
+                    float2 t[8];
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) t[w] = sh.ycol[4 * half + w][r];   // (slots above wmax: stale finite values)
-                    if (half == 0) y = sh.yrow[r];
+                    for (int w = 0; w < 8; ++w) t[w] = sh.ycol[w][r];      // (slots above wmax hold stale finite values)
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        if (4 * half + w <= wmax) {
+                    for (int w = 0; w < 8; ++w) {
+                        if (w <= wmax) {
                             y.x += t[w].x;
                             y.y += t[w].y;
                         }
                     }
                     if (p >= 0) {
-                        for (int j0 = 4 * half; j0 < j; j0 += 8) {
+                        for (int j0 = 0; j0 < j; j0 += 4) {
                             float2 vr[4], wr[4], g1[4], g2[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
@@ -400,14 +399,11 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                             }
                         }
                     }
-                    y.x = pn_pair_sum(y.x);
-                    y.y = pn_pair_sum(y.y);
-                    y = (r >= u) ? cmul(tau, y) : make_float2(0.f, 0.f);
+                    y = cmul(tau, y);
                 }
                 preg = y;
-                if (half == 0 && r == u) sh.pu = y;
+                if (r == u) sh.pu = y;
                 float2 dp = cmacc(make_float2(0.f, 0.f), y, vreg);   // conj(p) v
-                if (half) dp = make_float2(0.f, 0.f);
                 dp.x = pn_wave_sum(dp.x);
                 dp.y = pn_wave_sum(dp.y);
                 if (lane == 0) sh.red2[wave] = dp;
@@ -418,7 +414,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
             {
                 float2 dot = sh.red2[0];
 #pragma unroll
-                for (int q = 1; q < 8; ++q) {
+                for (int q = 1; q < 4; ++q) {
                     dot.x += sh.red2[q].x;
                     dot.y += sh.red2[q].y;
                 }
@@ -426,16 +422,23 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 al.x *= -0.5f;
                 al.y *= -0.5f;
                 wu = pn_fma_c(sh.pu, al, hu);
-                wreg = (r >= u) ? pn_fma_c(preg, al, vreg) : make_float2(0.f, 0.f);
-                if (half == 0) {
+                if (tid < D) {
+                    wreg = (r >= u) ? pn_fma_c(preg, al, vreg) : make_float2(0.f, 0.f);
                     sh.Vp[r][j] = vreg;
                     sh.Wp[r][j] = wreg;
                 }
             }
             mark(6);
         }
-        if (p == PN_NT - 1) break;
         __syncthreads();
+        // the panel's reflectors (rows u = 16 p + 1 + jj of the image, the layout the Q kernel reads) leave in one go
+        if (tid < D) {
+            for (int jj = (p < 0) ? 15 : 0; jj < 16; ++jj) {
+                const int uu = 16 * p + 1 + jj;
+                if (uu < D) Mg[(int64_t)uu * D + tid] = sh.Vp[tid][jj];
+            }
+        }
+        if (p == PN_NT - 1) break;
         // ---- trailing update on the matrix cores: tiles (I, J), I >= J >= p + 1:  T -= V_I W_J^H + W_I V_J^H
         //      re -= Vr Wr' + Vi Wi' + Wr Vr' + Wi Vi' ;  im -= Vi Wr' - Vr Wi' + Wi Vr' - Wr Vi'   (' = block column J)
         //      The A operands (rows of block row I; lane (m = c16, g) supplies k' = 4 g + s at step s) carry the signs,
@@ -505,7 +508,12 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
         if (tid == 0)
             for (int i = 0; i < 8; ++i) atomicAdd(&tdbg[i], tacc[i]);
     }
-    if (tid == 0) ecol[D] = 0.f;
+    __syncthreads();
+    for (int i = tid; i <= D; i += PN_THREADS) {
+        dcol[i] = sh.dbuf[i];
+        ecol[i] = (i < D) ? sh.ebuf[i] : 0.f;
+        if (i < D) Mg[(int64_t)D * D + i] = sh.taubuf[i];   // taus live in the consumed arrow slot
+    }
 }
 
 bool tridiag_panel_supported(int D) { return D == PN_D; }
