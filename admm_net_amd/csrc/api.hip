@@ -107,9 +107,11 @@ static void carve_chunk(Carver &c, int D, int64_t chunk, Ws *ws) {
     ws->w = c.take<float>(chunk * n);
     ws->w0 = c.take<float>(chunk * n);
     ws->logn = c.take<int>(chunk * 2);
+    ws->Tfac = nullptr;
     if (use_dc()) {
         ws->Wdc = c.take<float>(chunk * 3 * n * n);
         ws->VT = c.take<float>(chunk * n * 2 * D);
+        if (tridiag_panel_supported(D)) ws->Tfac = c.take<float2>(chunk * 17 * 256);
         ws->log = nullptr;
     } else {
         ws->log = c.take<LogRec>(chunk * ws->cap);
@@ -185,6 +187,7 @@ static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream
         const bool big = vgemm_big_supported(D);
         if ((rc = launch_dc(D + 1, nb, ws, status, st, with_v && !big))) return rc;
         if (!with_v) return ADMMNET_OK;
+        if (big && use_wy_back(D)) return launch_wy_apply(D, nb, ws, st);   // block reflectors applied to W: no explicit Q
         return big ? launch_vgemm_big(D, nb, ws, st) : launch_vgemm(D, nb, ws, st);
     }
     if ((rc = launch_tql(D + 1, nb, ws, status, st))) return rc;

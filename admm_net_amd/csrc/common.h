@@ -96,6 +96,7 @@ struct Ws {
     float *w, *w0;            // [chunk][n] eigenvalues, first row of W
     float *Wdc;               // [chunk][3][n][n] divide & conquer: two WT ping-pong buffers + U (null: QL path)
     float *VT;                // [chunk][n][2D] eigenvectors for the rebuild (= QV on the QL path)
+    float2 *Tfac;             // [chunk][17][16][16] T factors of the panel block reflectors (D = 256 path, else null)
     LogRec *log;              // [chunk][cap], 64-byte groups (eig_core.h)
     int *logn;                // [chunk][2]: records, status
     int64_t chunk;            // signals per chunk
@@ -124,6 +125,8 @@ int launch_tridiag_reg(int D, int64_t nb, const Ws &ws, hipStream_t st, const fl
 int launch_tridiag_big(int D, int64_t nb, const Ws &ws, hipStream_t st);   // tridiag_big.hip, 128 < D <= 256
 bool tridiag_panel_supported(int D);                                      // tridiag_panel.hip, D == 256
 int launch_tridiag_panel(int D, int64_t nb, const Ws &ws, hipStream_t st);
+bool use_wy_back(int D);                                                  // wy_apply.hip: V = Q W without forming Q
+int launch_wy_apply(int D, int64_t nb, const Ws &ws, hipStream_t st);     // wy_apply.hip
 // tql.hip
 int launch_tql(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st);
 // rotapply.hip

@@ -419,6 +419,7 @@ static int launch_tb(int D, int64_t nb, const Ws &ws, hipStream_t st) {
                            ws.eT);
         ADMM_HIP(hipGetLastError());
     }
+    if (use_panel(D) && use_wy_back(D)) return ADMMNET_OK;   // the back-transform applies the block reflectors itself
     hipLaunchKernelGGL(ungtr_big_kernel<NA>, dim3((unsigned)nb, (unsigned)((D + 127) / 128)), dim3(TB_THREADS), 0, st,
                        D, ws.Mbuf, ws.QV);
     ADMM_HIP(hipGetLastError());

@@ -49,6 +49,7 @@ struct PnShared {
     float2 g[32];                  // g[jj] = W_jj^H v, g[16 + jj] = V_jj^H v
     float2 red2[8];
     float2 pu;                     // p[u] of the current reflector
+    float2 Gp[16][16];             // Gp[k][i] = V_k^H v_i (k < i): strict upper triangle of the panel's Gram matrix
     int skip;                      // the current reflector is the identity
     float dbuf[PN_D + 4], ebuf[PN_D + 4];   // d, e and the taus are gathered here and written out once: a global store on
     float2 taubuf[PN_D];                    // the per-reflector path makes the next barrier wait for its completion
@@ -147,6 +148,7 @@ __device__ __forceinline__ float pn_quad_group_sum(float x0, float x1, float x2,
 template <bool TIMING>
 __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__restrict__ Mbuf, float *__restrict__ dT,
                                                                       float *__restrict__ eT,
+                                                                      float2 *__restrict__ Tfac,
                                                                       unsigned long long *__restrict__ tdbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     PnShared &sh = *reinterpret_cast<PnShared *>(smem);
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
         (&sh.Vp[0][0])[i] = make_float2(0.f, 0.f);
         (&sh.Wp[0][0])[i] = make_float2(0.f, 0.f);
     }
+    if (tid < 256) (&sh.Gp[0][0])[tid] = make_float2(0.f, 0.f);
     if (tid < D) sh.colbuf[tid] = Mg[(int64_t)D * D + tid];   // the arrow: column of the prologue reflector
     // (no barrier yet: the first one of the step loop orders these stores before any reader, and every global
     //  store below comes after at least one barrier, i.e. after every wave's matrix loads have been issued AND
@@ -358,7 +361,10 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                     }
                     acc.x = pn_row16_sum(acc.x + acc2.x);
                     acc.y = pn_row16_sum(acc.y + acc2.y);
-                    if (c16 == 0 && jj < j) sh.g[q] = acc;
+                    if (c16 == 0 && jj < j) {
+                        sh.g[q] = acc;
+                        if (q >= 16) sh.Gp[jj][j] = acc;   // V_jj^H v_j: kept for the block reflector's T factor
+                    }
                 }
             }
             mark(4);
@@ -437,6 +443,26 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 const int uu = 16 * p + 1 + jj;
                 if (uu < D) Mg[(int64_t)uu * D + tid] = sh.Vp[tid][jj];
             }
+        }
+        // ... and the T factor of the panel's block reflector  H_u0 H_u0+1 ... = I - Y T Y^H  (LAPACK clarft, forward /
+        // columnwise):  T[i][i] = tau_i,  T[0:i, i] = -tau_i T[0:i, 0:i] (Y[:, 0:i]^H y_i) -- the Gram entries are the
+        // panel dots the matrix-vector phase computed anyway.  Wave 7 (the one with the fewest tiles to update below),
+        // lane m = row m of T; slots without a reflector (prologue panel, u = D) have tau = 0.
+        if (Tfac != nullptr && wave == 7 && lane < 16) {
+            float2 Trow[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int uu = 16 * p + 1 + i;
+                const float2 gam = (uu >= 0 && uu < D) ? sh.taubuf[uu] : make_float2(0.f, 0.f);
+                float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < i; ++k) acc = pn_fma_c(acc, Trow[k], sh.Gp[k][i]);   // (T[m][k] = 0 for k < m)
+                const float2 t = cmul(gam, acc);
+                Trow[i] = (lane == i) ? gam : (lane < i ? make_float2(-t.x, -t.y) : make_float2(0.f, 0.f));
+            }
+            float2 *dst = Tfac + (bm * 17 + (p + 1)) * 256 + lane * 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[i] = Trow[i];
         }
         if (p == PN_NT - 1) break;
         // ---- trailing update on the matrix cores: tiles (I, J), I >= J >= p + 1:  T -= V_I W_J^H + W_I V_J^H
@@ -532,7 +558,7 @@ int launch_tridiag_panel(int D, int64_t nb, const Ws &ws, hipStream_t st) {
         ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_panel_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(tridiag_panel_kernel<true>, dim3((unsigned)nb), dim3(PN_THREADS), lds, st, ws.Mbuf, ws.dT,
-                           ws.eT, ptime);
+                           ws.eT, ws.Tfac, ptime);
         ADMM_HIP(hipGetLastError());
         ADMM_HIP(hipMemcpyAsync(hb, ptime, sizeof(hb), hipMemcpyDeviceToHost, st));
         ADMM_HIP(hipStreamSynchronize(st));
@@ -546,7 +572,7 @@ int launch_tridiag_panel(int D, int64_t nb, const Ws &ws, hipStream_t st) {
     ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_panel_kernel<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(tridiag_panel_kernel<false>, dim3((unsigned)nb), dim3(PN_THREADS), lds, st, ws.Mbuf, ws.dT, ws.eT,
-                       (unsigned long long *)nullptr);
+                       ws.Tfac, (unsigned long long *)nullptr);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }

@@ -1,0 +1,167 @@
+// wy_apply.hip -- K3'' for D = 256: back-transform of the divide & conquer eigenvectors WITHOUT forming Q,
+//   V = diag(1, Q') W,   Q' = H_0 H_1 ... H_{D-1},   H_u = I - tau_u v_u v_u^H
+// (second half of torch.linalg.eigh at /root/reference/admm_net.py:303), by the block reflectors of the panels the
+// tridiagonalisation worked in (tridiag_panel.hip; LAPACK cunmtr / clarfb, forward columnwise):
+//   X <- (I - Y T Y^H) X,   X = W[1:, :],  panels from the last to the first,
+// every product on the matrix cores (v_mfma_f32_16x16x4_f32).  Replaces ungtr_big_kernel (explicit Q, 16/3 n^3 flops on
+// the vector ALUs) + vgemm_big_kernel (Q W).
+//
+// One wave owns 16 columns of X for all 256 rows: sixteen 16 x 16 accumulator tiles (128 VGPRs), and keeps them in
+// registers through all 17 panels.  Per panel and wave:
+//   Z  = Y^H X    the X tiles ARE the B operands (accumulator layout = B-operand layout: lane -> column, the four
+//                 lane groups -> k), the A operands conj(Y) come from the LDS copy of the panel
+//   Zt = T Z      Z, just produced as an accumulator tile, is the B operand again
+//   X -= Y Zt     Zt as B operand, Y rows as A operands, accumulated straight into the X tiles
+// so no X / Z / Zt element ever moves between lanes or through memory.  A workgroup = 4 waves = 64 columns shares the
+// panel (Y: 256 x 16 complex = 36 KB with padding, T: 2 KB) through LDS; 5 workgroups per matrix cover the 257 columns.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace admmnet {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int WY_D = 256;
+constexpr int WY_THREADS = 256;
+constexpr int WY_PITCH = 18;    // float2 per LDS row of the panel (as tridiag_panel.hip)
+
+struct WyShared {
+    float2 Y[WY_D][WY_PITCH];
+    float2 T[16][WY_PITCH];
+};
+
+__global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *__restrict__ Mbuf,
+                                                                 const float2 *__restrict__ Tfac,
+                                                                 const float *__restrict__ Wbuf, int64_t wt_off,
+                                                                 float *__restrict__ VT) {
+    __shared__ WyShared sh;
+    constexpr int D = WY_D, n = D + 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    const int64_t bm = blockIdx.x;
+    const int cb = 4 * blockIdx.y + wave;          // column block of this wave: eigenvectors 16 cb .. 16 cb + 15
+    const bool live = 16 * cb < n;                 // (uniform) the last workgroup has one live wave (column 256)
+    const int col = 16 * cb + c16;
+    const float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
+    const float2 *Tg = Tfac + bm * 17 * 256;
+    const float *WT = Wbuf + bm * (int64_t)3 * n * n + wt_off;   // WT[c][i] = W[i][c]
+    float *Vb = VT + bm * ((int64_t)n * 2 * D);
+
+    // X = W[1:, 16 cb .. 16 cb + 15]: tile I, register q of lane (c16, g) = X[16 I + 4 g + q][col]  (real to begin with)
+    f32x4 xr[16], xi[16];
+#pragma unroll
+    for (int I = 0; I < 16; ++I) {
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live && col < n) {
+            const float *src = WT + (int64_t)col * n + 1 + 16 * I + 4 * g;
+            v = f32x4{src[0], src[1], src[2], src[3]};
+        }
+        xr[I] = v;
+        xi[I] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int pp = 16; pp >= 0; --pp) {
+        const int u0 = 16 * (pp - 1) + 1;          // reflector of slot jj: u0 + jj (absent outside 0 .. D - 1)
+        const int I0 = (u0 < 0 ? 0 : u0) >> 4;     // first block row the panel touches
+        __syncthreads();                           // the previous panel's LDS image is no longer read
+        // ---- the panel: Y[r][jj] = v_{u0 + jj}[r] (reflector row u of the image), T
+        for (int jj = 0; jj < 16; ++jj) {
+            const int uu = u0 + jj;
+            float2 y = make_float2(0.f, 0.f);
+            if (uu >= 0 && uu < D && tid >= 16 * I0) y = Mg[(int64_t)uu * D + tid];
+            sh.Y[tid][jj] = y;
+        }
+        sh.T[tid >> 4][tid & 15] = Tg[pp * 256 + tid];
+        __syncthreads();
+        if (!live) continue;                       // (uniform per wave; the barriers above are outside)
+        // ---- Z = Y^H X  (16 reflectors x 16 columns):  Zr = Yr Xr + Yi Xi,  Zi = Yr Xi - Yi Xr
+        f32x4 zr = f32x4{0.f, 0.f, 0.f, 0.f}, zi = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int I = 0; I < 16; ++I) {
+            if (I >= I0) {   // (uniform)
+                // step q: B = X register q (k = lane group g <-> row 16 I + 4 g + q), A[m = jj][k = g] = conj(Y[that row][jj])
+                const float xrq[4] = {xr[I].x, xr[I].y, xr[I].z, xr[I].w}, xiq[4] = {xi[I].x, xi[I].y, xi[I].z, xi[I].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float2 y = sh.Y[16 * I + 4 * g + q][c16];
+                    zr = __builtin_amdgcn_mfma_f32_16x16x4f32(y.x, xrq[q], zr, 0, 0, 0);
+                    zi = __builtin_amdgcn_mfma_f32_16x16x4f32(y.x, xiq[q], zi, 0, 0, 0);
+                    zr = __builtin_amdgcn_mfma_f32_16x16x4f32(y.y, xiq[q], zr, 0, 0, 0);
+                    zi = __builtin_amdgcn_mfma_f32_16x16x4f32(-y.y, xrq[q], zi, 0, 0, 0);
+                }
+            }
+        }
+        // ---- Zt = T Z:  step q: B = Z register q (k = g <-> reflector 4 g + q), A[m][k = g] = T[m][4 g + q]
+        f32x4 tr = f32x4{0.f, 0.f, 0.f, 0.f}, ti = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float zrq[4] = {zr.x, zr.y, zr.z, zr.w}, ziq[4] = {zi.x, zi.y, zi.z, zi.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float2 t = sh.T[c16][4 * g + q];
+                tr = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, zrq[q], tr, 0, 0, 0);
+                ti = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, ziq[q], ti, 0, 0, 0);
+                tr = __builtin_amdgcn_mfma_f32_16x16x4f32(-t.y, ziq[q], tr, 0, 0, 0);
+                ti = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, zrq[q], ti, 0, 0, 0);
+            }
+        }
+        // ---- X -= Y Zt:  step q: B = Zt register q (k = g <-> reflector 4 g + q), A[m = row][k = g] = Y[16 I + m][4 g + q]
+        {
+            const float trq[4] = {tr.x, tr.y, tr.z, tr.w}, tiq[4] = {ti.x, ti.y, ti.z, ti.w};
+#pragma unroll
+            for (int I = 0; I < 16; ++I) {
+                if (I >= I0) {   // (uniform)
+                    f32x4 re = xr[I], im = xi[I];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float2 y = sh.Y[16 * I + c16][4 * g + q];
+                        re = __builtin_amdgcn_mfma_f32_16x16x4f32(-y.x, trq[q], re, 0, 0, 0);
+                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(-y.x, tiq[q], im, 0, 0, 0);
+                        re = __builtin_amdgcn_mfma_f32_16x16x4f32(y.y, tiq[q], re, 0, 0, 0);
+                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(-y.y, trq[q], im, 0, 0, 0);
+                    }
+                    xr[I] = re;
+                    xi[I] = im;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // ---- V^T image for the rebuild: VT[c][rho] = Re V[rho][c], VT[c][D + rho] = Im V[rho][c]  (pitch 2 D)
+    if (live && col < n) {
+        float *dst = Vb + (int64_t)col * 2 * D + 4 * g;
+#pragma unroll
+        for (int I = 0; I < 16; ++I) {
+            *reinterpret_cast<float4 *>(dst + 16 * I) = make_float4(xr[I].x, xr[I].y, xr[I].z, xr[I].w);
+            *reinterpret_cast<float4 *>(dst + D + 16 * I) = make_float4(xi[I].x, xi[I].y, xi[I].z, xi[I].w);
+        }
+    }
+}
+
+// The block-reflector back-transform needs the T factors the panel tridiagonalisation writes; ADMMNET_BACK=q keeps the
+// explicit Q (ungtr_big_kernel) + vgemm_big_kernel pair for A/B runs.
+bool use_wy_back(int D) {
+    // (every switch that takes the tridiagonalisation or the tridiagonal solver off the panel / D&C route turns it off)
+    static const bool off = (getenv("ADMMNET_BACK") && !strcmp(getenv("ADMMNET_BACK"), "q")) ||
+                            (getenv("ADMMNET_TRIDIAG_BIG") && !strcmp(getenv("ADMMNET_TRIDIAG_BIG"), "sweep")) ||
+                            (getenv("ADMMNET_TRIDIAG") && !strcmp(getenv("ADMMNET_TRIDIAG"), "lds"));
+    return !off && use_dc() && tridiag_panel_supported(D);
+}
+
+int launch_wy_apply(int D, int64_t nb, const Ws &ws, hipStream_t st) {
+    ProfScope _prof(KC_ROTAPPLY, st);
+    if (nb <= 0) return ADMMNET_OK;
+    if (D != WY_D || !ws.Tfac || !ws.Wdc) {
+        set_error("wy_apply: D=%d unsupported (256 with the panel tridiagonalisation only)", D);
+        return ADMMNET_E_ARG;
+    }
+    const int n = D + 1;
+    hipLaunchKernelGGL(wy_apply_kernel, dim3((unsigned)nb, (unsigned)((n + 63) / 64)), dim3(WY_THREADS), 0, st, ws.Mbuf,
+                       ws.Tfac, ws.Wdc, dc_final_offset(n), ws.VT);
+    ADMM_HIP(hipGetLastError());
+    return ADMMNET_OK;
+}
+
+}  // namespace admmnet

@@ -39,6 +39,8 @@ VARIANTS = {
     "unfused_back": {"ADMMNET_FUSE_BACK": "0", "ADMMNET_ARROW": "0"},
     "tridiag_lds": {"ADMMNET_TRIDIAG": "lds", "ADMMNET_ARROW": "0"},
     "full_storage": {"ADMMNET_LEAN": "0"},
+    "sweep_big": {"ADMMNET_TRIDIAG_BIG": "sweep"},     # D = 256: per-reflector register sweep + explicit Q + Q W
+    "explicit_q": {"ADMMNET_BACK": "q"},               # D = 256: panel tridiagonalisation, explicit Q + Q W
 }
 
 
