@@ -56,6 +56,9 @@ SYMBOLS = {
                                           c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64,
                                           c_void_p]),
     "admmnet_regional_maxima_f64": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "admmnet_synth_batch": (c_int32, [c_int64, c_int32, c_int32, c_int32, ctypes.c_uint64, c_double, c_double, c_double,
+                                      c_double, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
     "admmnet_profile_enable": (c_int32, [c_int32]),
     "admmnet_profile_read": (c_int32, [c_void_p, c_void_p, c_int32]),
 }

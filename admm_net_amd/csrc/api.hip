@@ -617,4 +617,16 @@ int admmnet_regional_maxima_f64(const double *Z, int64_t B, int32_t nx, int32_t 
                         (hipStream_t)stream);
 }
 
+int admmnet_synth_batch(int64_t B, int32_t Nb, int32_t Nd, int32_t L, uint64_t seed, double snr_lo, double snr_hi,
+                        double snr_e, double rho, int32_t label_iters, void *y, void *b, float *sigma, float *tau, float *f,
+                        void *C, void *phi_label, void *stream) {
+    if (B < 1 || Nb < 1 || Nd < 1 || (int64_t)Nb * Nd > 4096 || L < 1 || L > 8 || !y || !b || !sigma || !tau || !f || !C ||
+        label_iters < 0) {
+        set_error("synth_batch: bad argument");
+        return ADMMNET_E_ARG;
+    }
+    return launch_synth(B, Nb, Nd, L, seed, snr_lo, snr_hi, snr_e, rho, label_iters, (float2 *)y, (float2 *)b, sigma, tau,
+                        f, (float2 *)C, (float2 *)phi_label, (hipStream_t)stream);
+}
+
 }  // extern "C"

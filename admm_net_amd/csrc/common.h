@@ -164,6 +164,11 @@ int launch_spectrum_tables(const double *taus, int nx, int xbase, const double *
 int launch_spectrum_main(const float2 *phi, int64_t B, int xbase, int ybase, const double2 *tabD, int nx,
                          const double2 *tabS, int ny, double *out, hipStream_t st);
 
+// synth.hip
+int launch_synth(int64_t B, int Nb, int Nd, int L, unsigned long long seed, double snr_lo, double snr_hi, double snr_e,
+                 double rho, int label_iters, float2 *y, float2 *b, float *sigma, float *tau, float *f, float2 *C,
+                 float2 *phi_label, hipStream_t st);
+
 // ---- optional per-kernel-class HIP-event profiler (bench.py roofline leg) ------
 enum KernelClass { KC_PREP = 0, KC_TRIDIAG, KC_TQL, KC_ROTAPPLY, KC_REBUILD, KC_ZSTEP, KC_HEAD, KC_SPECTRUM, KC_COUNT };
 struct ProfScope {   // records start/stop events on `st` around a launcher body when profiling is on

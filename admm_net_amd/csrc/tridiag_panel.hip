@@ -50,6 +50,7 @@ struct PnShared {
     float2 red2[8];
     float2 pu;                     // p[u] of the current reflector
     float2 Gp[16][16];             // Gp[k][i] = V_k^H v_i (k < i): strict upper triangle of the panel's Gram matrix
+    float2 Tl[16][16];             // T factor of the panel's block reflector, built one column per reflector
     int skip;                      // the current reflector is the identity
     float dbuf[PN_D + 4], ebuf[PN_D + 4];   // d, e and the taus are gathered here and written out once: a global store on
     float2 taubuf[PN_D];                    // the per-reflector path makes the next barrier wait for its completion
@@ -177,7 +178,10 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
         (&sh.Vp[0][0])[i] = make_float2(0.f, 0.f);
         (&sh.Wp[0][0])[i] = make_float2(0.f, 0.f);
     }
-    if (tid < 256) (&sh.Gp[0][0])[tid] = make_float2(0.f, 0.f);
+    if (tid < 256) {
+        (&sh.Gp[0][0])[tid] = make_float2(0.f, 0.f);
+        (&sh.Tl[0][0])[tid] = make_float2(0.f, 0.f);
+    }
     if (tid < D) sh.colbuf[tid] = Mg[(int64_t)D * D + tid];   // the arrow: column of the prologue reflector
     // (no barrier yet: the first one of the step loop orders these stores before any reader, and every global
     //  store below comes after at least one barrier, i.e. after every wave's matrix loads have been issued AND
@@ -277,6 +281,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                     sh.Vp[r][j] = make_float2(0.f, 0.f);
                     sh.Wp[r][j] = make_float2(0.f, 0.f);
                 }
+                if (tid < 16) sh.Tl[tid][j] = make_float2(0.f, 0.f);
                 continue;
             }
             // ---- D: y = M v with the resident half (+ the panel dots W^H v, V^H v)
@@ -370,6 +375,20 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
             mark(4);
             __syncthreads();   // (B4)
             // ---- E: assemble y, corrections, p = tau y, p^H v
+            //      Meanwhile wave 7 (idle here, like waves 4 .. 6) appends column j to the panel's T factor (LAPACK clarft,
+            //      forward / columnwise):  T[j][j] = tau_j,  T[0:j, j] = -tau_j T[0:j, 0:j] (Y[:, 0:j]^H y_j) -- the Gram
+            //      entries are the panel dots the matrix-vector phase has just left in Gp.  Lane m = row m of T.
+            if (wave == 7 && lane < 16 && p >= 0) {
+                const float2 gam = sh.taubuf[u];
+                float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 15; ++k) {
+                    const float2 tk = sh.Tl[lane][k], gk = sh.Gp[k][j];
+                    if (k >= lane && k < j) acc = pn_fma_c(acc, tk, gk);
+                }
+                const float2 t = cmul(gam, acc);
+                sh.Tl[lane][j] = (lane == j) ? gam : (lane < j ? make_float2(-t.x, -t.y) : make_float2(0.f, 0.f));
+            }
             if (tid < D) {
                 float2 y = make_float2(0.f, 0.f);
                 if (r >= u) {
@@ -444,25 +463,17 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 if (uu < D) Mg[(int64_t)uu * D + tid] = sh.Vp[tid][jj];
             }
         }
-        // ... and the T factor of the panel's block reflector  H_u0 H_u0+1 ... = I - Y T Y^H  (LAPACK clarft, forward /
-        // columnwise):  T[i][i] = tau_i,  T[0:i, i] = -tau_i T[0:i, 0:i] (Y[:, 0:i]^H y_i) -- the Gram entries are the
-        // panel dots the matrix-vector phase computed anyway.  Wave 7 (the one with the fewest tiles to update below),
-        // lane m = row m of T; slots without a reflector (prologue panel, u = D) have tau = 0.
+        // ... and the T factor of the panel's block reflector  H_u0 H_u0+1 ... = I - Y T Y^H  (built column by column
+        // during the panel, see phase E; the prologue "panel" holds the single reflector u = 0 in slot 15)
         if (Tfac != nullptr && wave == 7 && lane < 16) {
-            float2 Trow[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int uu = 16 * p + 1 + i;
-                const float2 gam = (uu >= 0 && uu < D) ? sh.taubuf[uu] : make_float2(0.f, 0.f);
-                float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-                for (int k = 0; k < i; ++k) acc = pn_fma_c(acc, Trow[k], sh.Gp[k][i]);   // (T[m][k] = 0 for k < m)
-                const float2 t = cmul(gam, acc);
-                Trow[i] = (lane == i) ? gam : (lane < i ? make_float2(-t.x, -t.y) : make_float2(0.f, 0.f));
-            }
             float2 *dst = Tfac + (bm * 17 + (p + 1)) * 256 + lane * 16;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dst[i] = Trow[i];
+            for (int i = 0; i < 16; ++i) {
+                float2 t = sh.Tl[lane][i];
+                if (p < 0) t = (lane == 15 && i == 15) ? sh.taubuf[0] : make_float2(0.f, 0.f);
+                if (16 * p + 1 + i >= D) t = make_float2(0.f, 0.f);   // slot without a reflector (u = D)
+                dst[i] = t;
+            }
         }
         if (p == PN_NT - 1) break;
         // ---- trailing update on the matrix cores: tiles (I, J), I >= J >= p + 1:  T -= V_I W_J^H + W_I V_J^H

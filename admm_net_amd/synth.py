@@ -63,3 +63,41 @@ def make_batch(batch, Nb, Nd, L=3, seed=20260104, snr_range=(5.0, 25.0), snr_e=7
     sigma = np.linalg.norm(e / b, axis=1) + 1.0
     truth = dict(tau=tau.astype(np.float32), f=f.astype(np.float32), C=C.astype(np.complex64))
     return y.astype(np.complex64), b.astype(np.complex64), sigma.astype(np.float32), truth
+
+
+def make_batch_device(batch, Nb, Nd, L=3, seed=20260104, snr_range=(5.0, 25.0), snr_e=7.0, device=None, labels=False,
+                      rho=1.0, label_iters=5):
+    """The same recipe generated ON the MI355X (csrc/synth.hip, one workgroup per sample): nothing crosses PCIe.
+
+    Returns (y [B,D] c64, b [B,D] c64, sigma [B] f32, truth dict of device tensors); with ``labels=True`` the dict
+    carries ``phi`` [B,D] c64 = the label DatasetGeneratorCreatePhi computes with admm_for_us (generate_data.py:410-463).
+    The random stream is the kernel's own counter-based generator (the reference seeds nothing), so samples differ from
+    ``make_batch`` with the same seed; the distributions are the same.
+    """
+    import ctypes
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    if device is None:
+        if not torch.cuda.is_available():
+            raise _lib.AdmmNetError("make_batch_device needs the GPU (use make_batch for host data)")
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    D = Nb * Nd
+    with torch.cuda.device(device):
+        y = torch.empty(batch, D, dtype=torch.complex64, device=device)
+        b = torch.empty(batch, D, dtype=torch.complex64, device=device)
+        sigma = torch.empty(batch, dtype=torch.float32, device=device)
+        tau = torch.empty(batch, L, dtype=torch.float32, device=device)
+        f = torch.empty(batch, L, dtype=torch.float32, device=device)
+        C = torch.empty(batch, L, dtype=torch.complex64, device=device)
+        phi = torch.empty(batch, D, dtype=torch.complex64, device=device) if labels else None
+        p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(lib.admmnet_synth_batch(batch, Nb, Nd, L, int(seed) & (2 ** 64 - 1), float(snr_range[0]),
+                                           float(snr_range[1]), float(snr_e), float(rho), int(label_iters), p(y), p(b),
+                                           p(sigma), p(tau), p(f), p(C), p(phi), stream), "admmnet_synth_batch")
+    truth = dict(tau=tau, f=f, C=C)
+    if labels:
+        truth["phi"] = phi
+    return y, b, sigma, truth

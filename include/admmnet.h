@@ -186,6 +186,17 @@ int admmnet_peak_search_f64(const void *phi, int64_t B, int32_t xbase, int32_t y
 int admmnet_regional_maxima_f64(const double *Z, int64_t B, int32_t nx, int32_t ny, int32_t max_peaks,
                                 double *peaks, int32_t *counts, void *stream);
 
+/* Batched scene synthesis + classical-solver labels on the device: generate_data.py:133-221 (_generate_single_sample,
+ * _generate_communication_symbols) and the phi label of DatasetGeneratorCreatePhi (:410-463 = admm_for_us(y, b, ...),
+ * which as written is the recursion phi_k = W (y / b + rho phi_{k-1}) stopped at min_iter).
+ *   outputs (device): y, b complex64 [B][Nb*Nd]; sigma float [B]; tau, f float [B][L]; C complex64 [B][L];
+ *   phi_label complex64 [B][Nb*Nd] or NULL.  snr_lo..snr_hi: range of the per-sample SNR in dB (equal = fixed);
+ *   snr_e: demodulation SNR (7); rho, label_iters: the classical solver's rho (1) and its iteration count (5).
+ *   Counter-based generator: (seed, sample index) fixes a sample regardless of B or launch geometry. */
+int admmnet_synth_batch(int64_t B, int32_t Nb, int32_t Nd, int32_t L, uint64_t seed, double snr_lo, double snr_hi,
+                        double snr_e, double rho, int32_t label_iters, void *y, void *b, float *sigma, float *tau,
+                        float *f, void *C, void *phi_label, void *stream);
+
 /* ---- measurement hooks (bench.py roofline leg) ---------------------------------
  * When enabled, every kernel launcher brackets its launch with HIP events on the
  * caller's stream.  admmnet_profile_read synchronises those events, returns the

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle's batched LAPACK calls on ~100 x 100 matrices only spin when OpenMP gets every core of a large host
+    # (a K = 10, B = 12 oracle forward took 10 s on the GPU box's host against 0.2 s on 4 threads): cap the CPU side.
+    import torch
+    torch.set_num_threads(min(4, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope="session")

@@ -21,11 +21,12 @@ from admm_net_amd.synth import make_batch  # noqa: E402
 from oracle import admm_net_ref as R  # noqa: E402
 
 dev = torch.device("cuda:0")
-Nb, Nd, K, B = 16, 16, int(os.environ.get("BISECT_K", "16")), 3
-sd = R.make_weights(Nb, Nd, K, seed=7, head=False, perturb=0.3)
+Nb, Nd, K, B = 16, 16, int(os.environ.get("BISECT_K", "16")), int(os.environ.get("BISECT_B", "3"))
+sd = R.make_weights(Nb, Nd, K, seed=int(os.environ.get("BISECT_WSEED", "7")), head=False,
+                    perturb=float(os.environ.get("BISECT_PERT", "0.3")))
 m = A.PhiEstADMMNet(M=Nb, N=Nd, num_layers=K).eval()
 m.load_state_dict(sd)
-y, b, s, _ = make_batch(B, Nb, Nd, seed=5)
+y, b, s, _ = make_batch(B, Nb, Nd, seed=int(os.environ.get("BISECT_DSEED", "5")))
 ty, tb, ts = torch.from_numpy(y), torch.from_numpy(b), torch.from_numpy(s)
 sd32, sd64 = R.cast_weights(sd, "f32"), R.cast_weights(sd, "f64")
 

@@ -1,0 +1,165 @@
+"""GPU (-m gpu): the rows SURVEY.md section 8f ranks 3-4 and BASELINE cfg5 -- device-side scene / label generation,
+the reference-format timing harness and checkpoint flow through the drop-in launcher, the cfg5 post-processing."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import admm_net_amd as A
+from admm_net_amd import classical, harness, ops, peak_search, synth
+from oracle import peak_search_ref as PO
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_device_scene_synthesis_follows_the_generator_recipe(dev):
+    """generate_data.py:133-221 on the device (csrc/synth.hip): model identities sample by sample, parameter ranges,
+    and that a sample depends on (seed, index) only."""
+    Nb, Nd, B = 8, 16, 64
+    y, b, s, t = synth.make_batch_device(B, Nb, Nd, seed=5, device=dev, snr_range=(20.0, 20.0))
+    y2, b2, s2, t2 = synth.make_batch_device(2 * B, Nb, Nd, seed=5, device=dev, snr_range=(20.0, 20.0))
+    assert torch.equal(y, y2[:B]) and torch.equal(b, b2[:B]) and torch.equal(s, s2[:B])
+    y3 = synth.make_batch_device(B, Nb, Nd, seed=6, device=dev)[0]
+    assert not torch.equal(y, y3)
+    yn, bn, sn = y.cpu().numpy().astype(np.complex128), b.cpu().numpy().astype(np.complex128), s.cpu().numpy()
+    tau, f, C = (t[k].cpu().numpy() for k in ("tau", "f", "C"))
+    assert (tau >= 0.1).all() and (tau <= 0.9).all() and (np.abs(f) <= 0.4).all()
+    assert abs(C.real.std() - 0.7) < 0.15 and abs(C.imag.std() - 0.7) < 0.15
+    assert np.allclose(np.abs(bn), 1.0, atol=1e-6)                                   # QPSK
+    ang = np.angle(bn) / (np.pi / 4)
+    assert np.allclose(ang, np.round(ang), atol=1e-5) and (np.round(ang).astype(int) % 2 != 0).all()
+    S, Dm = synth.steering(f.astype(np.float64), Nb), synth.steering(tau.astype(np.float64), Nd)
+    psi = np.einsum("bl,bli,blj->bij", C.astype(np.complex128), S, np.conj(Dm)).reshape(B, Nb * Nd)
+    # y = sig psi + w with sig = b + e a QPSK symbol: per entry, the nearest of the four candidates explains y to the noise
+    cands = np.exp(1j * (2 * np.pi * np.arange(4) / 4 + np.pi / 4))
+    resid = np.abs(yn[:, :, None] - cands[None, None, :] * psi[:, :, None]).min(axis=2)
+    snr = 10 * np.log10((np.abs(psi) ** 2).sum(1) / (resid ** 2).sum(1))
+    assert (snr > 18.0).all() and (snr < 26.0).all()                                  # nominal 20 dB
+    # sigma = ||e / b|| + 1: e != 0 where the demodulated symbol differs from the transmitted one
+    sig_hat = cands[np.abs(yn[:, :, None] - cands[None, None, :] * psi[:, :, None]).argmin(axis=2)]
+    e = sig_hat - bn
+    assert np.abs(sn - (np.linalg.norm(e / bn, axis=1) + 1.0)).max() < 1e-3
+    ser = (np.abs(e) > 1e-6).mean()
+    assert 0.0 < ser < 0.2                                                            # 7 dB demodulation noise
+
+
+def test_device_labels_equal_the_classical_solver(dev, capsys):
+    """DatasetGeneratorCreatePhi labels (generate_data.py:410-463): phi = admm_for_us(y, b, Nd, Nb, 1, sigma, opts)."""
+    Nb = Nd = 10
+    y, b, s, t = synth.make_batch_device(5, Nb, Nd, seed=11, device=dev, labels=True)
+    yn, bn, sn = y.cpu().numpy().astype(np.complex128), b.cpu().numpy().astype(np.complex128), s.cpu().numpy()
+    lab = t["phi"].cpu().numpy()
+    for i in range(5):
+        phi, it = classical.admm_for_us(yn[i], bn[i], Nd, Nb, 1, float(sn[i]),
+                                        {"eta_abs": 1e-7, "eta_rel": 1e-7, "max_iter": 100})
+        assert it == 5
+        # (the device label is computed from the float64 scene before its cast to complex64: 1e-6-class agreement)
+        assert np.abs(lab[i] - phi).max() <= 2e-5 * np.abs(phi).max()
+    capsys.readouterr()
+
+
+def test_time_net_harness_and_checkpoint_flow(dev, tmp_path):
+    """test_time_net.py:94-102,131-137 equivalent: checkpoint in train.py's format -> load -> 1-signal CPU-tensor calls
+    -> np.savetxt file in the format of results/time/time_net_5.txt."""
+    torch.manual_seed(0)
+    src = A.PhiEstADMMNet(num_layers=5, M=10, N=10, L=3)
+    ck = tmp_path / "best_model.pth"
+    harness.save_checkpoint(ck, src, epoch=3, best_val_loss=0.5, config={"num_layers": 5})
+    m = A.PhiEstADMMNet(num_layers=5, M=10, N=10, L=3)
+    harness.load_checkpoint(ck, m)
+    out = tmp_path / "time_net_5.txt"
+    t = harness.time_net(m, runs=4, out_path=out, seed=2)
+    back = np.loadtxt(out)
+    assert back.shape == (4,) and np.allclose(back, t) and (back > 0).all() and back[1:].max() < 1.0
+
+
+CALLER = r'''
+# a caller written like the reference's main_for_net.py / test/test_time_net.py: star imports, CPU tensors,
+# weights_only=False checkpoint load, .detach().numpy(), alt_peak_search, np.savetxt of the wall times
+from utils.mathUtils import *
+from utils.peakSearchUtils import *
+from admm import *
+import torch, time, sys
+from admm_net import PhiEstADMMNet
+Nb = Nd = 10
+f = np.array([-0.25, 0, 0.14]); tau = np.array([0.45, 0.25, 0.63]); C = np.array([-0.5 + 1j, 0.6 - 0.2j, 0.3 + 0.7j])
+S = np.zeros((Nb, 3), dtype=complex); D = np.zeros((Nd, 3), dtype=complex)
+for i in range(3):
+    S[:, i] = vander_vec(0, (Nb - 1) * f[i], Nb).reshape(-1)
+    D[:, i] = vander_vec(0, (Nd - 1) * tau[i], Nd).reshape(-1)
+Psi = kr(S, np.conj(D)) @ C.reshape(-1, 1)
+np.random.seed(0)
+times = []
+for run in range(3):
+    sig = pskmod(np.random.randint(0, 4, Nb * Nd), 4, np.pi / 4)
+    b = pskmod(pskdemod(awgn(sig, 7), 4, np.pi / 4), 4, np.pi / 4)
+    e = sig - b
+    real_y = np.diag(b + e) @ Psi
+    w = np.sqrt(1 / 2) * (np.random.randn(Nb * Nd, 1) + 1j * np.random.randn(Nb * Nd, 1))
+    y = real_y + np.sqrt(np.linalg.norm(real_y) ** 2 / (10 ** 2 * Nb * Nd)) * w
+    sigma = np.linalg.norm(e / b) + 1
+    ty = torch.from_numpy(y.flatten().reshape(1, -1)).to(torch.complex64)
+    tb = torch.from_numpy(b.reshape(1, -1)).to(torch.complex64)
+    ts = torch.from_numpy(sigma.reshape(1, -1)).to(torch.float32)
+    model = PhiEstADMMNet(num_layers=5, M=Nb, N=Nd, L=3)
+    checkpoint = torch.load(sys.argv[1], weights_only=False)
+    model.load_state_dict(checkpoint['model_state_dict'])
+    model.eval()
+    start = time.perf_counter()
+    phi = model(ty, tb, ts)
+    times.append(time.perf_counter() - start)
+    phi = phi.detach().numpy().flatten()
+    res = alt_peak_search({'phi': phi, 'xbase': Nb, 'ybase': Nd}, {'xstep': 1 / (10 * Nd), 'ystep': 1 / (10 * Nb), 'iter': 3})
+    res = sorted(res, key=lambda x: x[2], reverse=True)[:3]
+    assert len(res) == 3 and type(model).__module__ == 'admm_net_amd.modules'
+np.savetxt(sys.argv[2], times)
+print('CALLER OK')
+'''
+
+
+def test_reference_style_caller_runs_on_the_gpu_through_the_launcher(dev, tmp_path):
+    """The drop-in end to end on the MI355X: a script with the reference callers' exact usage pattern, run by
+    `python -m admm_net_amd.dropin`, gets the HIP forward behind `from admm_net import PhiEstADMMNet`."""
+    torch.manual_seed(1)
+    ck = tmp_path / "best_model.pth"
+    harness.save_checkpoint(ck, A.PhiEstADMMNet(num_layers=5, M=10, N=10, L=3), epoch=1)
+    (tmp_path / "utils").mkdir()
+    (tmp_path / "admm_net.py").write_text("raise ImportError('script-directory admm_net imported')\n")
+    (tmp_path / "caller.py").write_text(CALLER)
+    out = tmp_path / "time_net_5.txt"
+    r = subprocess.run([sys.executable, "-m", "admm_net_amd.dropin", str(tmp_path / "caller.py"), str(ck), str(out)],
+                       cwd=str(tmp_path), env={**os.environ, "PYTHONPATH": ROOT}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CALLER OK" in r.stdout, r.stderr[-3000:]
+    assert np.loadtxt(out).shape == (3,)
+
+
+def test_cfg5_post_processing_on_a_2048_atom_grid(dev):
+    """BASELINE cfg5: PhiEstADMMNet (16 x 16) followed by alt_peak_search on a 2048-atom coarse grid (bench.py's
+    options): device peak search == the oracle's literal alt_peak_search; K = 32 depth itself is covered by the
+    reference fixture phiest_16x16_K32_default in test_gpu_parity.py."""
+    Nb = Nd = 16
+    opts = {"xstep": 1.0 / 65, "ystep": 1.0 / 32, "iter": 2}
+    ax, ay = peak_search.coarse_axes(opts)
+    assert len(ax) * len(ay) == 2048
+    torch.manual_seed(5)
+    m = A.PhiEstADMMNet(M=Nb, N=Nd, num_layers=4).eval()
+    y, b, s, _ = synth.make_batch(3, Nb, Nd, seed=31, snr_range=(15.0, 25.0))
+    phi = m(torch.from_numpy(y).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(s).to(dev))
+    pk, cnt = ops.peak_search(phi, Nd, Nb, opts, max_peaks=64)
+    pk, cnt, ph = pk.cpu().numpy(), cnt.cpu().numpy(), phi.cpu().numpy()
+    for i in range(3):
+        want = PO.alt_peak_search_literal({"phi": ph[i].astype(np.complex128), "xbase": Nd, "ybase": Nb}, opts)
+        assert cnt[i] == want.shape[0] and 0 < cnt[i] <= 64
+        got = pk[i, :cnt[i]]
+        assert np.array_equal(got[:, :2], want[:, :2])
+        assert np.abs(got[:, 2] - want[:, 2]).max() <= 1e-9 * want[:, 2].max()

@@ -553,3 +553,46 @@ def test_arrow_model(arrow_model, name):
     assert np.abs(V.conj().T @ V - np.eye(n)).max() < 6e-6
     assert np.abs(lam - np.linalg.eigvalsh(A)).max() < 2e-6 * sc
     assert st[3] <= 30   # secular iterations per root
+
+
+# ---------------------------------------------------------------- reference-format tooling
+def test_checkpoint_roundtrip_in_train_py_format(tmp_path):
+    """train.py:306-314 writes {'epoch','model_state_dict','optimizer_state_dict','scheduler_state_dict',
+    'best_val_loss','config','history'}; main_for_net.py:100-101 loads checkpoint['model_state_dict'] into the class."""
+    from admm_net_amd import harness
+    torch.manual_seed(3)
+    m = A.ADMMNet(M=4, N=4, L=3, num_layers=3)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-4)                 # train.py:123-126
+    sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2)   # train.py:127-131
+    path = tmp_path / "best_model.pth"
+    harness.save_checkpoint(path, m, opt, sch, epoch=7, best_val_loss=0.125, config={"M": 4, "N": 4, "num_layers": 3},
+                            history={"train_loss": [1.0, 0.5], "val_loss": [1.1, 0.6]})
+    raw = torch.load(path, weights_only=True)
+    assert set(raw) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "best_val_loss",
+                        "config", "history"}
+    torch.manual_seed(99)
+    m2 = A.ADMMNet(M=4, N=4, L=3, num_layers=3)
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1e-3, weight_decay=1e-4)
+    sch2 = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt2, T_0=10, T_mult=2)
+    ck = harness.load_checkpoint(path, m2, opt2, sch2)
+    assert ck["epoch"] == 7 and ck["best_val_loss"] == 0.125 and ck["history"]["val_loss"] == [1.1, 0.6]
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    # the way the reference's inference scripts consume it
+    m3 = A.ADMMNet(M=4, N=4, L=3, num_layers=3)
+    m3.load_state_dict(torch.load(path, weights_only=True)["model_state_dict"])
+    assert torch.equal(m3.gLayers[1].value_net[0].weight, m.gLayers[1].value_net[0].weight)
+
+
+def test_time_admm_writes_the_reference_file_format(tmp_path):
+    """test_time_admm.py:104-110: np.savetxt of one wall time per run -> the format of results/time/time.txt."""
+    from admm_net_amd import harness
+    z = np.load(os.path.join(GOLD, "cfg1_data.npz"), allow_pickle=False)
+    out = tmp_path / "time.txt"
+    t = harness.time_admm(runs=4, out_path=out, seed=1, sig=z["sig"], e=z["e"], data_type=2)
+    back = np.loadtxt(out)
+    assert back.shape == (4,) and np.allclose(back, t) and (back > 0).all()
+    first = open(out).readline().strip()
+    assert "e" in first and len(first) >= 20            # '%.18e', as np.savetxt('time.txt', cur_time) writes
+    y, b, sigma = harness.demo_scene(np.random.default_rng(0))
+    assert y.shape == (100, 1) and b.shape == (100,) and sigma >= 1.0
