@@ -106,9 +106,25 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         sh.fail = 0;
     }
     for (int i = tid; i < 2 * DC_MAXLEAF; i += DC_THREADS) (&sh.mx[0][0])[i] = 0;
+    int bad = 0;
     for (int i = tid; i < n; i += DC_THREADS) {
         lam[i] = dg[i];
         e0[i] = (i < n - 1) ? eg[i] : 0.f;
+        bad |= !(isfinite(lam[i]) && isfinite(e0[i]));
+    }
+    // A non-finite tridiagonal (NaN / Inf in the input): report and leave.  torch.linalg.eigh raises on such input, and
+    // the rank-by-counting / deflation bookkeeping below would leave permutation slots unwritten and index with them.
+    if (__syncthreads_or(bad)) {
+        for (int i = tid; i < n; i += DC_THREADS) {
+            wout[bm * n + i] = 0.f;
+            w0out[bm * n + i] = 0.f;
+        }
+        for (int64_t i = tid; i < (int64_t)3 * n * n; i += DC_THREADS) WA[i] = 0.f;
+        if (tid == 0) {
+            logn[bm * 2 + 1] = 1;
+            if (status) atomicAdd(status, 1);
+        }
+        return;
     }
     // both ping-pong buffers start at zero: every level writes only inside its diagonal blocks and
     // the next level reads the (zero) off-diagonal blocks of the pair it merges

@@ -45,12 +45,12 @@ def test_device_scene_synthesis_follows_the_generator_recipe(dev):
     resid = np.abs(yn[:, :, None] - cands[None, None, :] * psi[:, :, None]).min(axis=2)
     snr = 10 * np.log10((np.abs(psi) ** 2).sum(1) / (resid ** 2).sum(1))
     assert (snr > 18.0).all() and (snr < 26.0).all()                                  # nominal 20 dB
-    # sigma = ||e / b|| + 1: e != 0 where the demodulated symbol differs from the transmitted one
-    sig_hat = cands[np.abs(yn[:, :, None] - cands[None, None, :] * psi[:, :, None]).argmin(axis=2)]
-    e = sig_hat - bn
-    assert np.abs(sn - (np.linalg.norm(e / bn, axis=1) + 1.0)).max() < 1e-3
-    ser = (np.abs(e) > 1e-6).mean()
-    assert 0.0 < ser < 0.2                                                            # 7 dB demodulation noise
+    # sigma = ||e / b|| + 1 with e = sig - b a difference of two QPSK symbols: |e|^2 is 0, 2 (neighbour) or 4 (opposite),
+    # so (sigma - 1)^2 is an even integer = 2 x (#neighbour errors) + 4 x (#opposite errors); 7 dB demodulation noise
+    # gives a few percent symbol errors
+    q = (sn.astype(np.float64) - 1.0) ** 2 / 2.0
+    assert np.abs(q - np.round(q)).max() < 1e-4
+    assert 0.0 < np.round(q).mean() / (Nb * Nd) < 0.2
 
 
 def test_device_labels_equal_the_classical_solver(dev, capsys):
@@ -155,11 +155,11 @@ def test_cfg5_post_processing_on_a_2048_atom_grid(dev):
     m = A.PhiEstADMMNet(M=Nb, N=Nd, num_layers=4).eval()
     y, b, s, _ = synth.make_batch(3, Nb, Nd, seed=31, snr_range=(15.0, 25.0))
     phi = m(torch.from_numpy(y).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(s).to(dev))
-    pk, cnt = ops.peak_search(phi, Nd, Nb, opts, max_peaks=64)
+    pk, cnt = ops.peak_search(phi, Nd, Nb, opts, max_peaks=256)
     pk, cnt, ph = pk.cpu().numpy(), cnt.cpu().numpy(), phi.cpu().numpy()
     for i in range(3):
         want = PO.alt_peak_search_literal({"phi": ph[i].astype(np.complex128), "xbase": Nd, "ybase": Nb}, opts)
-        assert cnt[i] == want.shape[0] and 0 < cnt[i] <= 64
+        assert cnt[i] == want.shape[0] and 0 < cnt[i] <= 256
         got = pk[i, :cnt[i]]
         assert np.array_equal(got[:, :2], want[:, :2])
         assert np.abs(got[:, 2] - want[:, 2]).max() <= 1e-9 * want[:, 2].max()
