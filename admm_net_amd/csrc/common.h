@@ -151,6 +151,9 @@ bool use_dc();                                                                  
 int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h,
                    float2 *G, float *rn, float *w_out, const Ws &ws, hipStream_t st, bool lower_only = false);
 int launch_vout(int n, int64_t nb, float2 *V, float *w, const Ws &ws, hipStream_t st);
+bool rebuild_big_supported(int D);                                                        // rebuild_big.hip, D == 256
+int launch_rebuild_big(int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G, float *rn,
+                       const Ws &ws, hipStream_t st, bool lower_only);
 // zstep.hip
 int launch_rn_sum(int64_t B, const float *rn, double *sum, hipStream_t st);
 int launch_mean_from_sum(const double *sum, int64_t B, float *mean, hipStream_t st);

@@ -15,6 +15,9 @@
 // Operands come straight from the planar transposed VT[c][rho] image, which
 // is exactly the MFMA A/B lane layout (lane&31 = row, lane>>5 = k), so loads
 // are 128-byte coalesced segments with no LDS staging.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace admmnet {
@@ -178,6 +181,14 @@ int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const 
     ProfScope _prof(KC_REBUILD, st);
     if (nb <= 0) return ADMMNET_OK;
     const int n = D + 1;
+    // D = 256: every tile resident, V^T read once (rebuild_big.hip); ADMMNET_REBUILD=tiles keeps the kernel below
+    static const bool tiles = getenv("ADMMNET_REBUILD") && !strcmp(getenv("ADMMNET_REBUILD"), "tiles");
+    if (!tiles && rebuild_big_supported(D)) {
+        int rc = launch_rebuild_big(nb, lw, phi, h, G, rn, ws, st, lower_only);
+        if (rc) return rc;
+        if (w_out) ADMM_HIP(hipMemcpyAsync(w_out, ws.w, sizeof(float) * nb * n, hipMemcpyDeviceToDevice, st));
+        return ADMMNET_OK;
+    }
     const size_t lds = sizeof(float) * (3 * ((n + 4) & ~3) + 2 * D + 8);
     hipLaunchKernelGGL(rebuild_kernel, dim3((unsigned)nb), dim3(RB_THREADS), lds, st, D, lw, ws.VT, ws.w,
                        ws.w0, phi, h, G, rn, lower_only ? 1 : 0);
