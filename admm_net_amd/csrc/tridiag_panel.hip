@@ -158,11 +158,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile ownership tests below are uniform branches
     const int c16_0 = lane & 15, g_0 = lane >> 4;
     int c16 = c16_0, g = g_0;
-    // Tile ownership by LOGICAL wave wl (block rows {wl, 15 - wl}); hardware waves k and k + 4 share a SIMD (waves are
-    // dealt to the SIMDs cyclically), and the pairing (wl, 7 - wl) makes every SIMD's tile count 34 - 4 J0 at every
-    // stage of the reduction -- with wl = k the first SIMD carried 12 tiles against 6 on the last at J0 = 8.
-    const int wl = (wave < 4) ? wave : 11 - wave;
-    int IA = wl, IB = 15 - wl;
+    int IA = wave, IB = 15 - wave;
     const int64_t bm = blockIdx.x;
     float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
     float *dcol = dT + bm * n, *ecol = eT + bm * n;
@@ -176,17 +172,6 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
         const float2 e0 = src[0], e1 = src[D], e2 = src[2 * D], e3 = src[3 * D];
         tr[s] = f32x4{e0.x, e1.x, e2.x, e3.x};
         ti[s] = f32x4{e0.y, e1.y, e2.y, e3.y};
-    }
-    // column 0 of M (rows of the wave's tiles in block column 0) -> Ap[.][16]: the prologue reflector needs it (below)
-#pragma unroll
-    for (int s = 0; s < 17; ++s) {
-        PN_SLOT_IJ(s, I, J)
-        if (J == 0 && c16 == 0) {
-            sh.Ap[16 * I + 4 * g + 0][16] = make_float2(tr[s].x, ti[s].x);
-            sh.Ap[16 * I + 4 * g + 1][16] = make_float2(tr[s].y, ti[s].y);
-            sh.Ap[16 * I + 4 * g + 2][16] = make_float2(tr[s].z, ti[s].z);
-            sh.Ap[16 * I + 4 * g + 3][16] = make_float2(tr[s].w, ti[s].w);
-        }
     }
     const float corner = Mg[(int64_t)D * D + D].x;
     for (int i = tid; i < D * PN_PITCH; i += PN_THREADS) {
@@ -228,7 +213,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
             g = g_0;
             asm volatile("" : "+v"(c16), "+v"(g));
             {   // the same for the wave's block rows: the ownership tests are re-derived (scalar compares) per step
-                int wv = wl;     // instead of ~100 precomputed conditions parked in spill lanes
+                int wv = wave;   // instead of ~100 precomputed conditions parked in spill lanes
                 asm volatile("" : "+s"(wv));
                 IA = wv;
                 IB = 15 - wv;
@@ -258,8 +243,6 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                     x = pn_fms_cc(x, wreg, hu);
                 }
                 xcol = x;
-                sh.vbuf[r] = (r >= u) ? x : make_float2(0.f, 0.f);   // x' = the column from its unit row down: the
-                                                                      // matrix-vector product starts on it (see phase E)
                 if (r == c) sh.dbuf[u] = x.x;
                 if (p < 0 && r == 0) sh.dbuf[0] = corner;
                 if (r == u) sh.alpha = x;
@@ -270,10 +253,38 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
             if (u >= D) break;         // c = D - 1: only d[D] was due (uniform)
             mark(0);
             __syncthreads();   // (B2)
-            // ---- D: y' = M x' with the resident half (+ the panel dots W^H x', V^H x').  The reflector is v = x' - beta e_u
-            //      (its unit entry alpha - beta against x'_u = alpha), so M v, W^H v, V^H v follow from these by one
-            //      column of M / one row of the panels -- and this phase does not wait for the norm and the Householder
-            //      scalars: one barrier and one LDS round trip less per reflector.
+            // ---- C: the reflector (scalars on the row waves only: the other four need no tau, just the H = I flag)
+            float2 tau = make_float2(0.f, 0.f);
+            if (wave < 4) {   // (uniform)
+                const float xn2 = (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
+                const float2 alpha = sh.alpha;
+                float beta, tre, tim, sr, si;
+                householder_c(alpha.x, alpha.y, xn2, beta, tre, tim, sr, si);
+                const float g2 = sr * sr + si * si;
+                tau = make_float2(tre * g2, tim * g2);   // unnormalised reflector: H = I - tau v v^H, v = (alpha - beta, x)
+                hu = make_float2(alpha.x - beta, alpha.y);
+                vreg = (r == u) ? hu : (r > u ? xcol : make_float2(0.f, 0.f));
+                sh.vbuf[r] = vreg;
+                if (tid == 0) {
+                    sh.ebuf[u] = beta;
+                    sh.taubuf[u] = tau;
+                    sh.skip = (tre == 0.f && tim == 0.f) ? 1 : 0;
+                }
+            }
+            mark(1);
+            __syncthreads();   // (B3)
+            if (__builtin_amdgcn_readfirstlane(sh.skip)) {        // H = I (uniform): v = 0, w = 0
+                hu = make_float2(0.f, 0.f);
+                wu = make_float2(0.f, 0.f);
+                wreg = make_float2(0.f, 0.f);
+                if (tid < D) {
+                    sh.Vp[r][j] = make_float2(0.f, 0.f);
+                    sh.Wp[r][j] = make_float2(0.f, 0.f);
+                }
+                if (tid < 16) sh.Tl[tid][j] = make_float2(0.f, 0.f);
+                continue;
+            }
+            // ---- D: y = M v with the resident half (+ the panel dots W^H v, V^H v)
             {
                 const int J0 = u >> 4;
                 v2f Ar01, Ar23, Ai01, Ai23, Br01, Br23, Bi01, Bi23;   // v at the rows of block rows IA / IB (planar pairs)
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                         const float tx = pn_quad_group_sum(cx[0], cx[1], cx[2], cx[3]);
                         const float ty = pn_quad_group_sum(cy[0], cy[1], cy[2], cy[3]);
                         const int Jl = JQ + ((g & 1) << 1) + (g >> 1);   // lane row g holds block column JQ + {0, 2, 1, 3}[g]
-                        if (Jl >= J0 && Jl <= IB) sh.ycol[wl][16 * Jl + c16] = make_float2(tx, ty);
+                        if (Jl >= J0 && Jl <= IB) sh.ycol[wave][16 * Jl + c16] = make_float2(tx, ty);
                     }
                     __builtin_amdgcn_sched_barrier(0);   // keep each pass's loads inside it (VGPR budget)
                 }
@@ -363,53 +374,22 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
             }
             mark(4);
             __syncthreads();   // (B4)
-            // ---- E: the reflector's scalars (every thread, identical inputs), then y = y' - beta M[:, u], the corrections
-            //      with the panel (dots fixed up the same way), p = tau y, p^H v
-            float2 tau;
-            float beta;
-            {
-                const float xn2 = (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
-                const float2 alpha = sh.alpha;
-                float tre, tim, sr, si;
-                householder_c(alpha.x, alpha.y, xn2, beta, tre, tim, sr, si);
-                const float g2 = sr * sr + si * si;
-                tau = make_float2(tre * g2, tim * g2);   // unnormalised reflector: H = I - tau v v^H, v = (alpha - beta, x)
-                hu = make_float2(alpha.x - beta, alpha.y);
-                if (tid == 0) {
-                    sh.ebuf[u] = beta;
-                    sh.taubuf[u] = tau;
-                }
-                if (tre == 0.f && tim == 0.f) {                   // H = I (uniform): v = 0, w = 0
-                    hu = make_float2(0.f, 0.f);
-                    wu = make_float2(0.f, 0.f);
-                    wreg = make_float2(0.f, 0.f);
-                    vreg = make_float2(0.f, 0.f);
-                    if (tid < D) {
-                        sh.Vp[r][j] = make_float2(0.f, 0.f);
-                        sh.Wp[r][j] = make_float2(0.f, 0.f);
-                    }
-                    if (tid < 16) sh.Tl[tid][j] = make_float2(0.f, 0.f);
-                    continue;
-                }
-            }
+            // ---- E: assemble y, corrections, p = tau y, p^H v
             //      Meanwhile wave 7 (idle here, like waves 4 .. 6) appends column j to the panel's T factor (LAPACK clarft,
             //      forward / columnwise):  T[j][j] = tau_j,  T[0:j, j] = -tau_j T[0:j, 0:j] (Y[:, 0:j]^H y_j) -- the Gram
-            //      entries are the panel dots of phase D (on x': fixed up by -beta conj(V[u][k])).  Lane m = row m of T.
+            //      entries are the panel dots the matrix-vector phase has just left in Gp.  Lane m = row m of T.
             if (wave == 7 && lane < 16 && p >= 0) {
+                const float2 gam = sh.taubuf[u];
                 float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
                 for (int k = 0; k < 15; ++k) {
-                    const float2 tk = sh.Tl[lane][k], vk = sh.Vp[u][k];
-                    float2 gk = sh.Gp[k][j];
-                    gk.x -= beta * vk.x;
-                    gk.y += beta * vk.y;
+                    const float2 tk = sh.Tl[lane][k], gk = sh.Gp[k][j];
                     if (k >= lane && k < j) acc = pn_fma_c(acc, tk, gk);
                 }
-                const float2 t = cmul(tau, acc);
-                sh.Tl[lane][j] = (lane == j) ? tau : (lane < j ? make_float2(-t.x, -t.y) : make_float2(0.f, 0.f));
+                const float2 t = cmul(gam, acc);
+                sh.Tl[lane][j] = (lane == j) ? gam : (lane < j ? make_float2(-t.x, -t.y) : make_float2(0.f, 0.f));
             }
             if (tid < D) {
-                vreg = (r == u) ? hu : (r > u ? xcol : make_float2(0.f, 0.f));
                 float2 y = make_float2(0.f, 0.f);
                 if (r >= u) {
                     const int J = r >> 4;
@@ -418,7 +398,6 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                     float2 t[8];
 #pragma unroll
                     for (int w = 0; w < 8; ++w) t[w] = sh.ycol[w][r];      // (slots above wmax hold stale finite values)
-                    const float2 au = (p >= 0 && j < 15) ? sh.Ap[r][j + 1] : sh.Ap[r][16];   // M[r][u], panel-start matrix
 #pragma unroll
                     for (int w = 0; w < 8; ++w) {
                         if (w <= wmax) {
@@ -426,28 +405,21 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                             y.y += t[w].y;
                         }
                     }
-                    y.x = fmaf(-beta, au.x, y.x);
-                    y.y = fmaf(-beta, (r == u) ? 0.f : au.y, y.y);
                     if (p >= 0) {
                         for (int j0 = 0; j0 < j; j0 += 4) {
-                            float2 vr[4], wr[4], g1[4], g2[4], vu[4], wq[4];
+                            float2 vr[4], wr[4], g1[4], g2[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 vr[q] = sh.Vp[r][j0 + q];
                                 wr[q] = sh.Wp[r][j0 + q];
                                 g1[q] = sh.g[j0 + q];
                                 g2[q] = sh.g[16 + j0 + q];
-                                vu[q] = sh.Vp[u][j0 + q];
-                                wq[q] = sh.Wp[u][j0 + q];
                             }
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 if (j0 + q < j) {
-                                    // W^H v = W^H x' - beta conj(W[u]),  V^H v = V^H x' - beta conj(V[u])
-                                    const float2 h1 = make_float2(fmaf(-beta, wq[q].x, g1[q].x), fmaf(beta, wq[q].y, g1[q].y));
-                                    const float2 h2 = make_float2(fmaf(-beta, vu[q].x, g2[q].x), fmaf(beta, vu[q].y, g2[q].y));
-                                    y = pn_fms_c(y, vr[q], h1);
-                                    y = pn_fms_c(y, wr[q], h2);
+                                    y = pn_fms_c(y, vr[q], g1[q]);
+                                    y = pn_fms_c(y, wr[q], g2[q]);
                                 }
                             }
                         }
@@ -557,13 +529,6 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                     }
                     if (J == P1) {   // (uniform) the next panel's columns, up to date: rows 16 I + 4 g + q, column c16
                         float2 *dst = &sh.Ap[16 * I + 4 * g][c16];
-                        dst[0] = make_float2(re.x, im.x);
-                        dst[PN_PITCH] = make_float2(re.y, im.y);
-                        dst[2 * PN_PITCH] = make_float2(re.z, im.z);
-                        dst[3 * PN_PITCH] = make_float2(re.w, im.w);
-                    }
-                    if (J == P1 + 1 && c16 == 0) {   // ... and the column behind them (its last reflector's unit column)
-                        float2 *dst = &sh.Ap[16 * I + 4 * g][16];
                         dst[0] = make_float2(re.x, im.x);
                         dst[PN_PITCH] = make_float2(re.y, im.y);
                         dst[2 * PN_PITCH] = make_float2(re.z, im.z);
