@@ -174,7 +174,11 @@ static bool use_arrow(int D) {
 static bool use_lean(int D) {
     static const bool on = !(getenv("ADMMNET_LEAN") && atoi(getenv("ADMMNET_LEAN")) == 0);
     static const bool lds = getenv("ADMMNET_TRIDIAG") && !strcmp(getenv("ADMMNET_TRIDIAG"), "lds");
-    return on && !lds && D <= 128 && use_arrow(D);
+    static const bool sweep = getenv("ADMMNET_TRIDIAG_BIG") && !strcmp(getenv("ADMMNET_TRIDIAG_BIG"), "sweep");
+    // D = 256 on the panel tridiagonalisation: the same idea in its "half image" form (prep.hip PM_HALF): lower-triangle
+    // G / Z, image of the lower 16-block triangle -- exactly the tiles tridiag_panel_kernel loads
+    if (D > 128) return on && !lds && !sweep && use_dc() && tridiag_panel_supported(D) && use_arrow(D);
+    return on && !lds && use_arrow(D);
 }
 
 static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool with_v = true,
@@ -382,7 +386,9 @@ int admmnet_layer_front(const admmnet_cfg *cfg, const float *W, int32_t k, const
         }
         if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, ws, false, st, false, lean))) return rc;
         const bool fused = fuse_back(D, ws);
-        if ((rc = eig_chunk(D, nb, ws, status, st, !fused, lean ? ws.Z + b0 * n * n : nullptr, phk, hk, lw))) return rc;
+        // (D <= 128: the tridiagonalisation's own loader forms A from the lower triangle of Z; D = 256 reads the half image)
+        if ((rc = eig_chunk(D, nb, ws, status, st, !fused, (lean && D <= 128) ? ws.Z + b0 * n * n : nullptr, phk, hk, lw)))
+            return rc;
         rc = fused ? launch_back_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, ws, st, lean)
                    : launch_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, ws, st, lean);
         if (rc) return rc;

@@ -46,6 +46,8 @@ constexpr int PM_FIRST = 1;      // layer 0: G = Z = 0, nothing is read
 constexpr int PM_ZZERO = 2;      // layer 1: stored Z is still zero (never written)
 constexpr int PM_PHI_ONLY = 4;   // last layer: only phi is needed (admm_net.py:757-764)
 constexpr int PM_NO_MATRIX = 8;  // layer 0 on the arrowhead path (arrow.hip): phi and h only, A is never formed
+constexpr int PM_HALF = 32;      // D = 256 (tridiag_panel.hip): G / Z streamed as lower triangles, the image written for the lower
+                                 // 16-block triangle only (diagonal blocks in full) -- the tiles that kernel loads
 constexpr int PM_LEAN = 16;      // G / Z kept as lower triangles, A built by the tridiagonalisation's own loader
                                  // (tridiag_reg.hip): only the lazy Z update streams here, 24 n^2 / 2 bytes per signal
 
@@ -167,6 +169,35 @@ __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
     const float corner_g = lw[S_CORNER_G], inv_rho_g = lw[S_INV_RHO_G];
     const float corner_zp = first ? 0.f : lw_prev[S_CORNER_Z];
     float2 *Mg = Mbuf + s * ((int64_t)D * D + D + 1);
+    if (mode & PM_HALF) {
+        // Lower triangle only (G, Z and C are Hermitian; row D = the arrow row lies in it): half the G / Z streams,
+        // about half the image.  Entries inside a diagonal 16-block also write their mirror, the arrow COLUMN of the
+        // image is the conjugate of the arrow row.
+        for (int idx = tid; idx < n * n; idx += PR_THREADS) {
+            const int i = idx / n, j = idx - i * n;
+            if (j > i) continue;
+            float2 zn = make_float2(0.f, 0.f);
+            if (!first) {
+                const float2 gij = Gs[idx];
+                const float2 zij = zzero ? make_float2(0.f, 0.f) : Zs[idx];
+                float2 c;
+                if (i < D) c = make_float2(i == j ? hp[i] : 0.f, 0.f);
+                else if (j == D) c = make_float2(corner_zp, 0.f);
+                else c = make_float2(phip[j].x, -phip[j].y);   // C[D][j] = conj(phi_prev_j)
+                zn = make_float2(zij.x + al * (gij.x - c.x), zij.y + al * (gij.y - c.y));
+                Zs[idx] = zn;
+            }
+            if (i == D) {
+                if (j == D) Mg[(int64_t)D * D + D] = make_float2(corner_g - inv_rho_g * zn.x, -inv_rho_g * zn.y);
+                else Mg[(int64_t)D * D + j] = make_float2(phis[j].x - inv_rho_g * zn.x, phis[j].y + inv_rho_g * zn.y);   // A[j][D] = conj(A[D][j])
+            } else {
+                const float2 a = make_float2((i == j ? hs[i] : 0.f) - inv_rho_g * zn.x, -inv_rho_g * zn.y);
+                Mg[(int64_t)i * D + j] = a;
+                if (i != j && (i >> 4) == (j >> 4)) Mg[(int64_t)j * D + i] = make_float2(a.x, -a.y);
+            }
+        }
+        return;
+    }
     for (int idx = tid; idx < n * n; idx += PR_THREADS) {
         const int i = idx / n, j = idx - i * n;
         float2 zn = make_float2(0.f, 0.f);
@@ -261,7 +292,7 @@ int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2
     if (k == 1) mode |= PM_ZZERO;
     if (phi_only) mode |= PM_PHI_ONLY;
     if (no_matrix && k == 0) mode |= PM_NO_MATRIX;
-    if (lean) mode |= PM_LEAN;
+    if (lean) mode |= (D > 128) ? PM_HALF : PM_LEAN;
     const int cur = k & 1, prv = cur ^ 1;
     const size_t lds = sizeof(float2) * 2 * D + sizeof(float) * (3 * D + kHid + 8);
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)nb), dim3(PR_THREADS), lds, st, D, mode, lw, lwp,
