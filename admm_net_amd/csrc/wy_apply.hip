@@ -41,8 +41,9 @@ __global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g = lane >> 4;
-    const int64_t bm = blockIdx.x;
-    const int cb = 4 * blockIdx.y + wave;          // column block of this wave: eigenvectors 16 cb .. 16 cb + 15
+    const int64_t bm = blockIdx.y;                 // (the five column slabs of a matrix are neighbours in the grid: they
+    const int cb = 4 * blockIdx.x + wave;          //  read the same reflectors at about the same time)
+                                                   // column block of this wave: eigenvectors 16 cb .. 16 cb + 15
     const bool live = 16 * cb < n;                 // (uniform) the last workgroup has one live wave (column 256)
     const int col = 16 * cb + c16;
     const float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
@@ -161,7 +162,7 @@ int launch_wy_apply(int D, int64_t nb, const Ws &ws, hipStream_t st) {
         return ADMMNET_E_ARG;
     }
     const int n = D + 1;
-    hipLaunchKernelGGL(wy_apply_kernel, dim3((unsigned)nb, (unsigned)((n + 63) / 64)), dim3(WY_THREADS), 0, st, ws.Mbuf,
+    hipLaunchKernelGGL(wy_apply_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)nb), dim3(WY_THREADS), 0, st, ws.Mbuf,
                        ws.Tfac, ws.Wdc, dc_final_offset(n), ws.VT);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
