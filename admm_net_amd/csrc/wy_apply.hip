@@ -64,19 +64,29 @@ __global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *_
         xi[I] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // the panel image travels global -> registers -> LDS; the NEXT panel's loads are issued before this panel's products,
+    // so their latency hides behind the matrix-core work instead of sitting between two barriers
+    float2 ypre[16], tpre;
+    auto gload = [&](int pp) {
+        const int u0 = 16 * (pp - 1) + 1, I0 = (u0 < 0 ? 0 : u0) >> 4;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int uu = u0 + jj;
+            ypre[jj] = (uu >= 0 && uu < D && tid >= 16 * I0) ? Mg[(int64_t)uu * D + tid] : make_float2(0.f, 0.f);
+        }
+        tpre = Tg[pp * 256 + tid];
+    };
+    gload(16);
     for (int pp = 16; pp >= 0; --pp) {
         const int u0 = 16 * (pp - 1) + 1;          // reflector of slot jj: u0 + jj (absent outside 0 .. D - 1)
         const int I0 = (u0 < 0 ? 0 : u0) >> 4;     // first block row the panel touches
         __syncthreads();                           // the previous panel's LDS image is no longer read
         // ---- the panel: Y[r][jj] = v_{u0 + jj}[r] (reflector row u of the image), T
-        for (int jj = 0; jj < 16; ++jj) {
-            const int uu = u0 + jj;
-            float2 y = make_float2(0.f, 0.f);
-            if (uu >= 0 && uu < D && tid >= 16 * I0) y = Mg[(int64_t)uu * D + tid];
-            sh.Y[tid][jj] = y;
-        }
-        sh.T[tid >> 4][tid & 15] = Tg[pp * 256 + tid];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) sh.Y[tid][jj] = ypre[jj];
+        sh.T[tid >> 4][tid & 15] = tpre;
         __syncthreads();
+        if (pp > 0) gload(pp - 1);
         if (!live) continue;                       // (uniform per wave; the barriers above are outside)
         // ---- Z = Y^H X  (16 reflectors x 16 columns):  Zr = Yr Xr + Yi Xi,  Zi = Yr Xi - Yi Xr
         //      (Splitting this 256-term accumulation into block-local sums added pairwise was tried for accuracy: the
