@@ -67,6 +67,8 @@ __device__ __forceinline__ float pn_row16_sum(float x) {
     return x;
 }
 // sum over the four 16-lane rows of the wave, lane by lane (x of lanes l, l ^ 16, l ^ 32, l ^ 48): every lane gets it
+// (inline asm on purpose: the compiler's __builtin_amdgcn_permlane16/32_swap returned wrong sums here -- with identical
+//  operands it folds the two results into one, and the hidden-copy workaround still failed the n = 257 test)
 __device__ __forceinline__ float pn_group_sum(float x) {
     float a = x, b = x;
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
@@ -231,16 +233,22 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                             vc[q] = sh.Vp[c][j0 + q];
                             wc[q] = sh.Wp[c][j0 + q];
                         }
+                        // eight independent products, tree sum: the serial form was a 16-deep dependent fma chain per pass
+                        float2 t[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            if (j0 + q < j - 1) {
-                                x = pn_fms_cc(x, vr[q], wc[q]);
-                                x = pn_fms_cc(x, wr[q], vc[q]);
-                            }
+                            const bool on = j0 + q < j - 1;
+                            const float2 a = cmulc(vr[q], wc[q]), b2 = cmulc(wr[q], vc[q]);
+                            t[q] = on ? make_float2(a.x + b2.x, a.y + b2.y) : make_float2(0.f, 0.f);
                         }
+                        x.x -= (t[0].x + t[1].x) + (t[2].x + t[3].x);
+                        x.y -= (t[0].y + t[1].y) + (t[2].y + t[3].y);
                     }
-                    x = pn_fms_cc(x, vreg, wu);      // column j - 1 from registers: (V, W)[c][j - 1] = (hu, wu)
-                    x = pn_fms_cc(x, wreg, hu);
+                    {
+                        const float2 a = cmulc(vreg, wu), b2 = cmulc(wreg, hu);   // column j - 1 from registers:
+                        x.x -= a.x + b2.x;                                        // (V, W)[c][j - 1] = (hu, wu)
+                        x.y -= a.y + b2.y;
+                    }
                 }
                 xcol = x;
                 if (r == c) sh.dbuf[u] = x.x;
@@ -415,13 +423,15 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                                 g1[q] = sh.g[j0 + q];
                                 g2[q] = sh.g[16 + j0 + q];
                             }
+                            float2 t[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                if (j0 + q < j) {
-                                    y = pn_fms_c(y, vr[q], g1[q]);
-                                    y = pn_fms_c(y, wr[q], g2[q]);
-                                }
+                                const bool on = j0 + q < j;
+                                const float2 a = cmul(vr[q], g1[q]), b2 = cmul(wr[q], g2[q]);
+                                t[q] = on ? make_float2(a.x + b2.x, a.y + b2.y) : make_float2(0.f, 0.f);
                             }
+                            y.x -= (t[0].x + t[1].x) + (t[2].x + t[3].x);
+                            y.y -= (t[0].y + t[1].y) + (t[2].y + t[3].y);
                         }
                     }
                     y = cmul(tau, y);
