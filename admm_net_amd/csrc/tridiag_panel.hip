@@ -78,6 +78,23 @@ __device__ __forceinline__ float pn_group_sum(float x) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
     return a + b;
 }
+// the same for two values at once (re / im): the volatile asm blocks of two separate calls cannot overlap, one block
+// with both swaps can
+__device__ __forceinline__ void pn_group_sum2(float &x, float &y) {
+    float a = x, b = x, c = y, d = y;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    x = a + b;
+    y = c + d;
+    a = x;
+    b = x;
+    c = y;
+    d = y;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    x = a + b;
+    y = c + d;
+}
 // x + (x of the neighbouring lane l ^ 1): DPP quad_perm [1, 0, 3, 2]
 __device__ __forceinline__ float pn_pair_sum(float x) {
     return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
@@ -140,6 +157,19 @@ __device__ __forceinline__ float pn_quad_group_sum(float x0, float x1, float x2,
     float a = x0 + x1, b = x2 + x3;
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
     return a + b;
+}
+
+// ... two such quadruples (re / im) in the same two asm blocks
+__device__ __forceinline__ void pn_quad_group_sum2(const float (&x)[4], const float (&y)[4], float &tx, float &ty) {
+    float x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3], y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\ts_nop 1"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
+    float a = x0 + x1, b = x2 + x3, c = y0 + y1, d = y2 + y3;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    tx = a + b;
+    ty = c + d;
 }
 
 // slot s of wave w: tile (IB, s) for s <= IB, tile (IA, 16 - s) otherwise   (IA = w, IB = 15 - w)
@@ -309,12 +339,15 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 for (int JQ = 0; JQ < PN_NT; JQ += 4) {
                     if (JQ + 3 >= J0 && JQ <= IB) {   // (uniform) four block columns per pass: one joint lane reduction
                         float cx[4], cy[4];
+                        float2 vJq[4];   // the pass's four column slices of v, all in flight before the first product
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) vJq[k] = sh.vbuf[16 * (JQ + k) + c16];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int J = JQ + k;
                             v2f Cr = z2, Ci = z2;
                             if (J >= J0 && J <= IB) {   // (uniform)
-                                const float2 vJ = sh.vbuf[16 * J + c16];
+                                const float2 vJ = vJq[k];
                                 const float mB = (J == IB) ? 0.f : 1.f, mA = (J == IA) ? 0.f : 1.f;
                                 pn_tile_mv(tr[J], ti[J], make_float2(vJ.x * mB, vJ.y * mB), Br01, Br23, Bi01, Bi23, PBr01,
                                            PBr23, PBi01, PBi23, Cr, Ci);
@@ -325,8 +358,8 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                             cx[k] = Cr.x + Cr.y;
                             cy[k] = Ci.x + Ci.y;
                         }
-                        const float tx = pn_quad_group_sum(cx[0], cx[1], cx[2], cx[3]);
-                        const float ty = pn_quad_group_sum(cy[0], cy[1], cy[2], cy[3]);
+                        float tx, ty;
+                        pn_quad_group_sum2(cx, cy, tx, ty);
                         const int Jl = JQ + ((g & 1) << 1) + (g >> 1);   // lane row g holds block column JQ + {0, 2, 1, 3}[g]
                         if (Jl >= J0 && Jl <= IB) sh.ycol[wave][16 * Jl + c16] = make_float2(tx, ty);
                     }
@@ -439,8 +472,9 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 preg = y;
                 if (r == u) sh.pu = y;
                 float2 dp = cmacc(make_float2(0.f, 0.f), y, vreg);   // conj(p) v
-                dp.x = pn_wave_sum(dp.x);
-                dp.y = pn_wave_sum(dp.y);
+                dp.x = pn_row16_sum(dp.x);
+                dp.y = pn_row16_sum(dp.y);
+                pn_group_sum2(dp.x, dp.y);
                 if (lane == 0) sh.red2[wave] = dp;
             }
             mark(5);
