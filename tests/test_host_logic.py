@@ -596,3 +596,17 @@ def test_time_admm_writes_the_reference_file_format(tmp_path):
     assert "e" in first and len(first) >= 20            # '%.18e', as np.savetxt('time.txt', cur_time) writes
     y, b, sigma = harness.demo_scene(np.random.default_rng(0))
     assert y.shape == (100, 1) and b.shape == (100,) and sigma >= 1.0
+
+
+def test_host_models_under_sanitizers(tmp_path):
+    """SURVEY section 5 (sanitizers; the GPU pool has no device ASAN): the scalar cores shared with the HIP kernels, built
+    with -fsanitize=address,undefined and driven over every host-model entry point."""
+    hm = os.path.join(ROOT, "tests", "host_model")
+    exe = str(tmp_path / "sanitize_main")
+    cmd = ["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I",
+           os.path.join(ROOT, "admm_net_amd", "csrc")] + [os.path.join(hm, f) for f in
+           ("sanitize_main.cpp", "eigh_model.cpp", "dc_model.cpp", "arrow_model.cpp")] + ["-o", exe]
+    subprocess.check_call(cmd)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
+    assert r.returncode == 0 and "sanitize ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
