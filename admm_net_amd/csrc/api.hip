@@ -108,10 +108,14 @@ static void carve_chunk(Carver &c, int D, int64_t chunk, Ws *ws) {
     ws->w0 = c.take<float>(chunk * n);
     ws->logn = c.take<int>(chunk * 2);
     ws->Tfac = nullptr;
+    ws->Tail = nullptr;
     if (use_dc()) {
         ws->Wdc = c.take<float>(chunk * 3 * n * n);
         ws->VT = c.take<float>(chunk * n * 2 * D);
-        if (tridiag_panel_supported(D)) ws->Tfac = c.take<float2>(chunk * 17 * 256);
+        if (tridiag_panel_supported(D)) {
+            ws->Tfac = c.take<float2>(chunk * 17 * 256);
+            ws->Tail = c.take<float2>(chunk * tridiag_panel_tail_elems());
+        }
         ws->log = nullptr;
     } else {
         ws->log = c.take<LogRec>(chunk * ws->cap);

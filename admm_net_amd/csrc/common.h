@@ -97,6 +97,7 @@ struct Ws {
     float *Wdc;               // [chunk][3][n][n] divide & conquer: two WT ping-pong buffers + U (null: QL path)
     float *VT;                // [chunk][n][2D] eigenvectors for the rebuild (= QV on the QL path)
     float2 *Tfac;             // [chunk][17][16][16] T factors of the panel block reflectors (D = 256 path, else null)
+    float2 *Tail;             // [chunk][36][4][64] trailing 128 x 128 tile set between the stages of tridiag_panel
     LogRec *log;              // [chunk][cap], 64-byte groups (eig_core.h)
     int *logn;                // [chunk][2]: records, status
     int64_t chunk;            // signals per chunk
@@ -125,6 +126,7 @@ int launch_tridiag_reg(int D, int64_t nb, const Ws &ws, hipStream_t st, const fl
 int launch_tridiag_big(int D, int64_t nb, const Ws &ws, hipStream_t st);   // tridiag_big.hip, 128 < D <= 256
 bool tridiag_panel_supported(int D);                                      // tridiag_panel.hip, D == 256
 int launch_tridiag_panel(int D, int64_t nb, const Ws &ws, hipStream_t st);
+int64_t tridiag_panel_tail_elems();                                       // float2 per matrix of Ws::Tail
 bool use_wy_back(int D);                                                  // wy_apply.hip: V = Q W without forming Q
 int launch_wy_apply(int D, int64_t nb, const Ws &ws, hipStream_t st);     // wy_apply.hip
 // tql.hip

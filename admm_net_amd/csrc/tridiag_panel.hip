@@ -26,6 +26,7 @@
 // handled as column 15 of a virtual panel -1 whose other columns are zero.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -34,26 +35,29 @@ namespace admmnet {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int PN_D = 256;
-constexpr int PN_THREADS = 512;
-constexpr int PN_NT = 16;          // tiles per dimension
 constexpr int PN_PITCH = 18;       // float2 per panel row: 16 columns + 2 pad (144 B rows: 16-byte aligned, spread over banks)
+constexpr int PN_TAIL_TILES = 36;  // lower block triangle of the 128 x 128 trailing matrix handed from stage to stage
 
+// One STAGE of the reduction works on the trailing DL x DL matrix (DL = 16 NT rows, M-rows R0 = D - DL ...) with NT / 2
+// waves.  The first stage (NT = 16, HEAD) starts from the image, later ones from the tile set the previous stage left.
+template <int NT>
 struct PnShared {
-    float2 Vp[PN_D][PN_PITCH];     // panel reflectors (unnormalised), row r = M-row
-    float2 Wp[PN_D][PN_PITCH];     // panel w vectors
-    float2 Ap[PN_D][PN_PITCH];     // block column p of the panel-start matrix (the 16 columns the panel reduces)
-    float2 colbuf[PN_D];           // the arrow: column of the prologue reflector
-    float2 vbuf[PN_D];             // current reflector (zero above its unit position)
-    float2 yrow[PN_D];             // row-form part of M v (written by the owner wave of each block row)
-    float2 ycol[8][PN_D];          // column-form partials per wave
+    static constexpr int DL = 16 * NT, NW = NT / 2;
+    float2 Vp[DL][PN_PITCH];       // panel reflectors (unnormalised), row r = local M-row
+    float2 Wp[DL][PN_PITCH];       // panel w vectors
+    float2 Ap[DL][PN_PITCH];       // block column p of the panel-start matrix (the 16 columns the panel reduces)
+    float2 colbuf[DL];             // the arrow: column of the prologue reflector
+    float2 vbuf[DL];               // current reflector (zero above its unit position)
+    float2 yrow[DL];               // row-form part of M v (written by the owner wave of each block row)
+    float2 ycol[NW][DL];           // column-form partials per wave
     float2 g[32];                  // g[jj] = W_jj^H v, g[16 + jj] = V_jj^H v
     float2 red2[8];
     float2 pu;                     // p[u] of the current reflector
     float2 Gp[16][16];             // Gp[k][i] = V_k^H v_i (k < i): strict upper triangle of the panel's Gram matrix
     float2 Tl[16][16];             // T factor of the panel's block reflector, built one column per reflector
     int skip;                      // the current reflector is the identity
-    float dbuf[PN_D + 4], ebuf[PN_D + 4];   // d, e and the taus are gathered here and written out once: a global store on
-    float2 taubuf[PN_D];                    // the per-reflector path makes the next barrier wait for its completion
+    float dbuf[DL + 4], ebuf[DL + 4];       // d, e and the taus are gathered here and written out once: a global store on
+    float2 taubuf[DL];                      // the per-reflector path makes the next barrier wait for its completion
     float red[8];
     float2 alpha;
 };
@@ -172,49 +176,76 @@ __device__ __forceinline__ void pn_quad_group_sum2(const float (&x)[4], const fl
     ty = c + d;
 }
 
-// slot s of wave w: tile (IB, s) for s <= IB, tile (IA, 16 - s) otherwise   (IA = w, IB = 15 - w)
+// slot s of wave w: tile (IB, s) for s <= IB, tile (IA, NT - s) otherwise   (IA = w, IB = NT - 1 - w)
 #define PN_SLOT_IJ(s, I, J)            \
     int I, J;                          \
     if ((s) <= IB) { I = IB; J = (s); } \
-    else { I = IA; J = 16 - (s); }
+    else { I = IA; J = NT - (s); }
 
-template <bool TIMING>
-__global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__restrict__ Mbuf, float *__restrict__ dT,
-                                                                      float *__restrict__ eT,
-                                                                      float2 *__restrict__ Tfac,
-                                                                      unsigned long long *__restrict__ tdbg) {
+// tile t(I, J) = I (I + 1) / 2 + J of the hand-over set, register q of lane l at ((t * 4 + q) * 64 + l): the accumulator
+// layout itself, so both sides move whole 512-byte wave rows
+__device__ __forceinline__ int64_t pn_tail_at(int I, int J, int q, int lane) {
+    return ((int64_t)(I * (I + 1) / 2 + J) * 4 + q) * 64 + lane;
+}
+
+template <int NT, bool HEAD, bool TIMING>
+__global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__restrict__ Mbuf, float *__restrict__ dT,
+                                                                   float *__restrict__ eT, float2 *__restrict__ Tfac,
+                                                                   float2 *__restrict__ Tail, int pstop,
+                                                                   unsigned long long *__restrict__ tdbg) {
+    static_assert(NT % 4 == 0 && NT <= 16 && (HEAD == (NT == 16)), "stage geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    PnShared &sh = *reinterpret_cast<PnShared *>(smem);
+    using Shared = PnShared<NT>;
+    Shared &sh = *reinterpret_cast<Shared *>(smem);
     constexpr int D = PN_D, n = D + 1;
+    constexpr int DL = 16 * NT, NW = NT / 2, RW = DL / 64, THREADS = 64 * NW;   // RW row waves, NW tile waves
+    constexpr int R0 = D - DL, P0 = 16 - NT;                                    // first M-row / panel of this stage
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile ownership tests below are uniform branches
     const int c16_0 = lane & 15, g_0 = lane >> 4;
     int c16 = c16_0, g = g_0;
-    int IA = wave, IB = 15 - wave;
+    int IA = wave, IB = NT - 1 - wave;
     const int64_t bm = blockIdx.x;
     float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
     float *dcol = dT + bm * n, *ecol = eT + bm * n;
+    float2 *tail = Tail + bm * (PN_TAIL_TILES * 256);
 
     // ---- load the Hermitian half into the accumulator layout
-    f32x4 tr[17], ti[17];
+    f32x4 tr[NT + 1], ti[NT + 1];
 #pragma unroll
-    for (int s = 0; s < 17; ++s) {
+    for (int s = 0; s < NT + 1; ++s) {
         PN_SLOT_IJ(s, I, J)
-        const float2 *src = Mg + (int64_t)(16 * I + 4 * g) * D + 16 * J + c16;
-        const float2 e0 = src[0], e1 = src[D], e2 = src[2 * D], e3 = src[3 * D];
-        tr[s] = f32x4{e0.x, e1.x, e2.x, e3.x};
-        ti[s] = f32x4{e0.y, e1.y, e2.y, e3.y};
+        if constexpr (HEAD) {
+            const float2 *src = Mg + (int64_t)(16 * I + 4 * g) * D + 16 * J + c16;
+            const float2 e0 = src[0], e1 = src[D], e2 = src[2 * D], e3 = src[3 * D];
+            tr[s] = f32x4{e0.x, e1.x, e2.x, e3.x};
+            ti[s] = f32x4{e0.y, e1.y, e2.y, e3.y};
+        } else {
+            const float2 e0 = tail[pn_tail_at(I, J, 0, lane)], e1 = tail[pn_tail_at(I, J, 1, lane)],
+                         e2 = tail[pn_tail_at(I, J, 2, lane)], e3 = tail[pn_tail_at(I, J, 3, lane)];
+            tr[s] = f32x4{e0.x, e1.x, e2.x, e3.x};
+            ti[s] = f32x4{e0.y, e1.y, e2.y, e3.y};
+            if (J == 0) {   // (uniform) the first panel's columns
+                float2 *dst = &sh.Ap[16 * I + 4 * g][c16];
+                dst[0] = e0;
+                dst[PN_PITCH] = e1;
+                dst[2 * PN_PITCH] = e2;
+                dst[3 * PN_PITCH] = e3;
+            }
+        }
     }
-    const float corner = Mg[(int64_t)D * D + D].x;
-    for (int i = tid; i < D * PN_PITCH; i += PN_THREADS) {
+    float corner = 0.f;
+    if constexpr (HEAD) corner = Mg[(int64_t)D * D + D].x;
+    for (int i = tid; i < DL * PN_PITCH; i += THREADS) {
         (&sh.Vp[0][0])[i] = make_float2(0.f, 0.f);
         (&sh.Wp[0][0])[i] = make_float2(0.f, 0.f);
     }
-    if (tid < 256) {
-        (&sh.Gp[0][0])[tid] = make_float2(0.f, 0.f);
-        (&sh.Tl[0][0])[tid] = make_float2(0.f, 0.f);
+    for (int i = tid; i < 256; i += THREADS) {
+        (&sh.Gp[0][0])[i] = make_float2(0.f, 0.f);
+        (&sh.Tl[0][0])[i] = make_float2(0.f, 0.f);
     }
-    if (tid < D) sh.colbuf[tid] = Mg[(int64_t)D * D + tid];   // the arrow: column of the prologue reflector
+    if constexpr (HEAD)
+        if (tid < D) sh.colbuf[tid] = Mg[(int64_t)D * D + tid];   // the arrow: column of the prologue reflector
     // (no barrier yet: the first one of the step loop orders these stores before any reader, and every global
     //  store below comes after at least one barrier, i.e. after every wave's matrix loads have been issued AND
     //  their results consumed into registers by the slot loop above)
@@ -236,7 +267,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
         }
     };
 
-    for (int p = -1; p < PN_NT; ++p) {
+    for (int p = HEAD ? -1 : 0; p < NT; ++p) {
         for (int j = (p < 0) ? 15 : 0; j < 16; ++j) {
             const int c = 16 * p + j, u = c + 1;
             // the lane coordinates are re-derived per step from an opaque copy: otherwise every LDS address of the
@@ -248,10 +279,10 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 int wv = wave;   // instead of ~100 precomputed conditions parked in spill lanes
                 asm volatile("" : "+s"(wv));
                 IA = wv;
-                IB = 15 - wv;
+                IB = NT - 1 - wv;
             }
             // ---- B: bring the column up to date with the panel's earlier reflectors; d, alpha, |x|^2
-            if (tid < D) {
+            if (tid < DL) {
                 float2 x = (p >= 0) ? sh.Ap[r][j] : sh.colbuf[r];
                 if (r >= c && p >= 0 && j > 0) {
                     for (int j0 = 0; j0 < j - 1; j0 += 4) {   // four columns per pass: all 16 loads in flight together
@@ -282,19 +313,22 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 }
                 xcol = x;
                 if (r == c) sh.dbuf[u] = x.x;
-                if (p < 0 && r == 0) sh.dbuf[0] = corner;
+                if (HEAD && p < 0 && r == 0) sh.dbuf[0] = corner;
                 if (r == u) sh.alpha = x;
                 float pn = (r > u) ? (x.x * x.x + x.y * x.y) : 0.f;
                 pn = pn_wave_sum(pn);
                 if (lane == 0) sh.red[wave] = pn;
             }
-            if (u >= D) break;         // c = D - 1: only d[D] was due (uniform)
+            if (u >= DL) break;        // c = DL - 1: only d[D] was due (uniform)
             mark(0);
             __syncthreads();   // (B2)
             // ---- C: the reflector (scalars on the row waves only: the other four need no tau, just the H = I flag)
             float2 tau = make_float2(0.f, 0.f);
-            if (wave < 4) {   // (uniform)
-                const float xn2 = (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
+            if (wave < RW) {   // (uniform)
+                float xn2;
+                if constexpr (RW == 4) xn2 = (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
+                else if constexpr (RW == 2) xn2 = sh.red[0] + sh.red[1];
+                else xn2 = sh.red[0] + sh.red[1] + sh.red[2];
                 const float2 alpha = sh.alpha;
                 float beta, tre, tim, sr, si;
                 householder_c(alpha.x, alpha.y, xn2, beta, tre, tim, sr, si);
@@ -315,7 +349,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 hu = make_float2(0.f, 0.f);
                 wu = make_float2(0.f, 0.f);
                 wreg = make_float2(0.f, 0.f);
-                if (tid < D) {
+                if (tid < DL) {
                     sh.Vp[r][j] = make_float2(0.f, 0.f);
                     sh.Wp[r][j] = make_float2(0.f, 0.f);
                 }
@@ -336,7 +370,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 const v2f z2 = v2f{0.f, 0.f};
                 v2f PAr01 = z2, PAr23 = z2, PAi01 = z2, PAi23 = z2, PBr01 = z2, PBr23 = z2, PBi01 = z2, PBi23 = z2;
 #pragma unroll
-                for (int JQ = 0; JQ < PN_NT; JQ += 4) {
+                for (int JQ = 0; JQ < NT; JQ += 4) {
                     if (JQ + 3 >= J0 && JQ <= IB) {   // (uniform) four block columns per pass: one joint lane reduction
                         float cx[4], cy[4];
                         float2 vJq[4];   // the pass's four column slices of v, all in flight before the first product
@@ -352,7 +386,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                                 pn_tile_mv(tr[J], ti[J], make_float2(vJ.x * mB, vJ.y * mB), Br01, Br23, Bi01, Bi23, PBr01,
                                            PBr23, PBi01, PBi23, Cr, Ci);
                                 if (J <= IA)
-                                    pn_tile_mv(tr[16 - J], ti[16 - J], make_float2(vJ.x * mA, vJ.y * mA), Ar01, Ar23, Ai01,
+                                    pn_tile_mv(tr[NT - J], ti[NT - J], make_float2(vJ.x * mA, vJ.y * mA), Ar01, Ar23, Ai01,
                                                Ai23, PAr01, PAr23, PAi01, PAi23, Cr, Ci);
                             }
                             cx[k] = Cr.x + Cr.y;
@@ -396,20 +430,24 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 // panel dots: dot id q = 4 wave + g : q < 16 -> W_q^H v, else V_{q-16}^H v; the 16 lanes of a group
                 // stride the rows (v is zero above its unit row, so all sixteen 16-row blocks are summed: fixed trip
                 // count, all loads in flight together)
-                if (p >= 0 && 4 * (wave & 3) < j) {   // (uniform) at least one of this wave's four columns exists
-                    const int q = 4 * wave + g, jj = q & 15;
-                    float2 acc = make_float2(0.f, 0.f), acc2 = make_float2(0.f, 0.f);
-                    const float2(*X)[PN_PITCH] = (q < 16) ? sh.Wp : sh.Vp;
 #pragma unroll
-                    for (int i = 0; i < PN_NT; i += 2) {
-                        acc = cmacc(acc, X[16 * i + c16][jj], sh.vbuf[16 * i + c16]);
-                        acc2 = cmacc(acc2, X[16 * i + 16 + c16][jj], sh.vbuf[16 * i + 16 + c16]);
-                    }
-                    acc.x = pn_row16_sum(acc.x + acc2.x);
-                    acc.y = pn_row16_sum(acc.y + acc2.y);
-                    if (c16 == 0 && jj < j) {
-                        sh.g[q] = acc;
-                        if (q >= 16) sh.Gp[jj][j] = acc;   // V_jj^H v_j: kept for the block reflector's T factor
+                for (int q0 = 0; q0 < 32; q0 += 4 * NW) {   // (one pass with eight waves)
+                    const int qw = q0 + 4 * wave;           // (uniform) first of this wave's four dots of the pass
+                    if (p >= 0 && qw < 32 && (qw & 15) < j) {   // (uniform) at least one of the four columns exists
+                        const int q = qw + g, jj = q & 15;
+                        float2 acc = make_float2(0.f, 0.f), acc2 = make_float2(0.f, 0.f);
+                        const float2(*X)[PN_PITCH] = (q < 16) ? sh.Wp : sh.Vp;
+#pragma unroll
+                        for (int i = 0; i < NT; i += 2) {
+                            acc = cmacc(acc, X[16 * i + c16][jj], sh.vbuf[16 * i + c16]);
+                            acc2 = cmacc(acc2, X[16 * i + 16 + c16][jj], sh.vbuf[16 * i + 16 + c16]);
+                        }
+                        acc.x = pn_row16_sum(acc.x + acc2.x);
+                        acc.y = pn_row16_sum(acc.y + acc2.y);
+                        if (c16 == 0 && jj < j) {
+                            sh.g[q] = acc;
+                            if (q >= 16) sh.Gp[jj][j] = acc;   // V_jj^H v_j: kept for the block reflector's T factor
+                        }
                     }
                 }
             }
@@ -419,7 +457,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
             //      Meanwhile wave 7 (idle here, like waves 4 .. 6) appends column j to the panel's T factor (LAPACK clarft,
             //      forward / columnwise):  T[j][j] = tau_j,  T[0:j, j] = -tau_j T[0:j, 0:j] (Y[:, 0:j]^H y_j) -- the Gram
             //      entries are the panel dots the matrix-vector phase has just left in Gp.  Lane m = row m of T.
-            if (wave == 7 && lane < 16 && p >= 0) {
+            if (wave == NW - 1 && lane < 16 && p >= 0) {
                 const float2 gam = sh.taubuf[u];
                 float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
@@ -430,17 +468,17 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 const float2 t = cmul(gam, acc);
                 sh.Tl[lane][j] = (lane == j) ? gam : (lane < j ? make_float2(-t.x, -t.y) : make_float2(0.f, 0.f));
             }
-            if (tid < D) {
+            if (tid < DL) {
                 float2 y = make_float2(0.f, 0.f);
                 if (r >= u) {
                     const int J = r >> 4;
                     y = sh.yrow[r];
-                    const int wmax = min(7, 15 - J);
-                    float2 t[8];
+                    const int wmax = min(NW - 1, NT - 1 - J);
+                    float2 t[NW];
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) t[w] = sh.ycol[w][r];      // (slots above wmax hold stale finite values)
+                    for (int w = 0; w < NW; ++w) t[w] = sh.ycol[w][r];      // (slots above wmax hold stale finite values)
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) {
+                    for (int w = 0; w < NW; ++w) {
                         if (w <= wmax) {
                             y.x += t[w].x;
                             y.y += t[w].y;
@@ -483,7 +521,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
             {
                 float2 dot = sh.red2[0];
 #pragma unroll
-                for (int q = 1; q < 4; ++q) {
+                for (int q = 1; q < RW; ++q) {
                     dot.x += sh.red2[q].x;
                     dot.y += sh.red2[q].y;
                 }
@@ -491,7 +529,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 al.x *= -0.5f;
                 al.y *= -0.5f;
                 wu = pn_fma_c(sh.pu, al, hu);
-                if (tid < D) {
+                if (tid < DL) {
                     wreg = (r >= u) ? pn_fma_c(preg, al, vreg) : make_float2(0.f, 0.f);
                     sh.Vp[r][j] = vreg;
                     sh.Wp[r][j] = wreg;
@@ -501,25 +539,31 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
         }
         __syncthreads();
         // the panel's reflectors (rows u = 16 p + 1 + jj of the image, the layout the Q kernel reads) leave in one go
-        if (tid < D) {
+        if (tid < DL) {
             for (int jj = (p < 0) ? 15 : 0; jj < 16; ++jj) {
                 const int uu = 16 * p + 1 + jj;
-                if (uu < D) Mg[(int64_t)uu * D + tid] = sh.Vp[tid][jj];
+                if (uu < DL) Mg[(int64_t)(R0 + uu) * D + R0 + tid] = sh.Vp[tid][jj];
+            }
+        }
+        if constexpr (!HEAD) {   // the reflectors are zero above this stage's rows
+            for (int i = tid; i < 16 * R0; i += THREADS) {
+                const int uu = 16 * p + 1 + i / R0;
+                if (uu < DL) Mg[(int64_t)(R0 + uu) * D + i % R0] = make_float2(0.f, 0.f);
             }
         }
         // ... and the T factor of the panel's block reflector  H_u0 H_u0+1 ... = I - Y T Y^H  (built column by column
         // during the panel, see phase E; the prologue "panel" holds the single reflector u = 0 in slot 15)
-        if (Tfac != nullptr && wave == 7 && lane < 16) {
-            float2 *dst = Tfac + (bm * 17 + (p + 1)) * 256 + lane * 16;
+        if (Tfac != nullptr && wave == NW - 1 && lane < 16) {
+            float2 *dst = Tfac + (bm * 17 + (P0 + p + 1)) * 256 + lane * 16;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float2 t = sh.Tl[lane][i];
                 if (p < 0) t = (lane == 15 && i == 15) ? sh.taubuf[0] : make_float2(0.f, 0.f);
-                if (16 * p + 1 + i >= D) t = make_float2(0.f, 0.f);   // slot without a reflector (u = D)
+                if (16 * p + 1 + i >= DL) t = make_float2(0.f, 0.f);  // slot without a reflector (u = D)
                 dst[i] = t;
             }
         }
-        if (p == PN_NT - 1) break;
+        if (p == NT - 1) break;
         // ---- trailing update on the matrix cores: tiles (I, J), I >= J >= p + 1:  T -= V_I W_J^H + W_I V_J^H
         //      re -= Vr Wr' + Vi Wi' + Wr Vr' + Wi Vi' ;  im -= Vi Wr' - Vr Wi' + Wi Vr' - Wr Vi'   (' = block column J)
         //      The A operands (rows of block row I; lane (m = c16, g) supplies k' = 4 g + s at step s) carry the signs,
@@ -544,7 +588,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                 nWr[s] = -w.x; nWi[s] = -w.y; pWr[s] = w.x;
             }
 #pragma unroll
-            for (int J = 0; J < PN_NT; ++J) {
+            for (int J = 0; J < NT; ++J) {
                 if (J >= P1 && J <= I) {   // (uniform)
                     float2 bV[4], bW[4];
 #pragma unroll
@@ -552,7 +596,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                         bV[s] = sh.Vp[16 * J + c16][4 * g + s];
                         bW[s] = sh.Wp[16 * J + c16][4 * g + s];
                     }
-                    f32x4 re = half ? tr[16 - J] : tr[J], im = half ? ti[16 - J] : ti[J];
+                    f32x4 re = half ? tr[NT - J] : tr[J], im = half ? ti[NT - J] : ti[J];
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         re = __builtin_amdgcn_mfma_f32_16x16x4f32(nVr[s], bW[s].x, re, 0, 0, 0);
@@ -565,8 +609,8 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
                         im = __builtin_amdgcn_mfma_f32_16x16x4f32(pWr[s], bV[s].y, im, 0, 0, 0);
                     }
                     if (half) {
-                        tr[16 - J] = re;
-                        ti[16 - J] = im;
+                        tr[NT - J] = re;
+                        ti[NT - J] = im;
                     } else {
                         tr[J] = re;
                         ti[J] = im;
@@ -583,6 +627,20 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
             }
         }
         mark(7);
+        if (p == pstop - 1) {   // (uniform) hand the trailing matrix to the next stage: tiles (I, J), I >= J >= pstop
+#pragma unroll
+            for (int s = 0; s < NT + 1; ++s) {
+                PN_SLOT_IJ(s, I, J)
+                if (J >= pstop) {   // (uniform)
+                    const f32x4 re = tr[s], im = ti[s];
+                    tail[pn_tail_at(I - pstop, J - pstop, 0, lane)] = make_float2(re.x, im.x);
+                    tail[pn_tail_at(I - pstop, J - pstop, 1, lane)] = make_float2(re.y, im.y);
+                    tail[pn_tail_at(I - pstop, J - pstop, 2, lane)] = make_float2(re.z, im.z);
+                    tail[pn_tail_at(I - pstop, J - pstop, 3, lane)] = make_float2(re.w, im.w);
+                }
+            }
+            break;
+        }
         __syncthreads();   // the next panel's columns (Ap) are complete; Vp / Wp may be rewritten
     }
     if constexpr (TIMING) {
@@ -590,46 +648,69 @@ __global__ __launch_bounds__(PN_THREADS, 2) void tridiag_panel_kernel(float2 *__
             for (int i = 0; i < 8; ++i) atomicAdd(&tdbg[i], tacc[i]);
     }
     __syncthreads();
-    for (int i = tid; i <= D; i += PN_THREADS) {
-        dcol[i] = sh.dbuf[i];
-        ecol[i] = (i < D) ? sh.ebuf[i] : 0.f;
-        if (i < D) Mg[(int64_t)D * D + i] = sh.taubuf[i];   // taus live in the consumed arrow slot
+    // d, e, taus of the columns this stage reduced: local indices (HEAD: 0, else 1) .. min(16 pstop, DL)
+    const int hi = (pstop < NT) ? 16 * pstop : DL;
+    for (int i = tid + (HEAD ? 0 : 1); i <= hi; i += THREADS) {
+        dcol[R0 + i] = sh.dbuf[i];
+        ecol[R0 + i] = (i < DL) ? sh.ebuf[i] : 0.f;
+        if (i < DL) Mg[(int64_t)D * D + R0 + i] = sh.taubuf[i];   // taus live in the consumed arrow slot
     }
 }
 
 bool tridiag_panel_supported(int D) { return D == PN_D; }
+int64_t tridiag_panel_tail_elems() { return PN_TAIL_TILES * 256; }
+
+// Stage split: the first kernel (8 waves, one workgroup per CU: the register-resident half of the 256 x 256 matrix)
+// reduces panels 0 .. 7, the second (4 waves, 69 KB of LDS: two workgroups per CU) the trailing 128 x 128 matrix.  Every
+// reflector is a chain of five barrier-separated latency-bound phases, so two independent matrices per CU overlap where
+// one leaves the CU idle.  ADMMNET_PN_SPLIT=0 runs the whole reduction in the first kernel.
+static int pn_split() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("ADMMNET_PN_SPLIT");
+        v = (e && !strcmp(e, "0")) ? 0 : 8;
+    }
+    return v;
+}
+
+template <int NT, bool HEAD, bool TIMING>
+static int pn_launch_stage(int64_t nb, const Ws &ws, int pstop, unsigned long long *tdbg, hipStream_t st) {
+    const size_t lds = sizeof(PnShared<NT>);
+    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_panel_kernel<NT, HEAD, TIMING>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((tridiag_panel_kernel<NT, HEAD, TIMING>), dim3((unsigned)nb), dim3(32 * NT), lds, st, ws.Mbuf,
+                       ws.dT, ws.eT, ws.Tfac, ws.Tail, pstop, tdbg);
+    ADMM_HIP(hipGetLastError());
+    return ADMMNET_OK;
+}
 
 int launch_tridiag_panel(int D, int64_t nb, const Ws &ws, hipStream_t st) {
     if (!tridiag_panel_supported(D)) {
         set_error("tridiag_panel: D=%d unsupported (256 only)", D);
         return ADMMNET_E_ARG;
     }
-    const size_t lds = sizeof(PnShared);
+    const bool split = pn_split() == 8 && ws.Tail != nullptr;
     static const bool timing = getenv("ADMMNET_PN_TIMING") != nullptr;   // developer aid, never on by default
     if (timing) {
-        unsigned long long *ptime = nullptr, hb[8];
+        unsigned long long *ptime = nullptr, hb[16];
         ADMM_HIP(hipMalloc(&ptime, sizeof(hb)));
         ADMM_HIP(hipMemsetAsync(ptime, 0, sizeof(hb), st));
-        ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_panel_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(tridiag_panel_kernel<true>, dim3((unsigned)nb), dim3(PN_THREADS), lds, st, ws.Mbuf, ws.dT,
-                           ws.eT, ws.Tfac, ptime);
-        ADMM_HIP(hipGetLastError());
+        int rc = pn_launch_stage<16, true, true>(nb, ws, split ? 8 : 16, ptime, st);
+        if (rc == ADMMNET_OK && split) rc = pn_launch_stage<8, false, true>(nb, ws, 8, ptime + 8, st);
+        if (rc != ADMMNET_OK) return rc;
         ADMM_HIP(hipMemcpyAsync(hb, ptime, sizeof(hb), hipMemcpyDeviceToHost, st));
         ADMM_HIP(hipStreamSynchronize(st));
         ADMM_HIP(hipFree(ptime));
         static const char *nm[8] = {"column+norm", "reflector", "matvec tiles", "row flush", "panel dots", "assemble+dot", "w+store", "mfma update"};
-        fprintf(stderr, "[tridiag_panel timing] nb=%lld  mean cycles per matrix (wave 0, barrier waits fall into the NEXT phase):\n",
+        fprintf(stderr, "[tridiag_panel timing] nb=%lld  mean cycles per matrix (wave 0, barrier waits fall into the NEXT phase), stage 1 | stage 2:\n",
                 (long long)nb);
-        for (int i = 0; i < 8; ++i) fprintf(stderr, "   %-14s %10.0f\n", nm[i], (double)hb[i] / (double)nb);
+        for (int i = 0; i < 8; ++i)
+            fprintf(stderr, "   %-14s %10.0f %10.0f\n", nm[i], (double)hb[i] / (double)nb, (double)hb[8 + i] / (double)nb);
         return ADMMNET_OK;
     }
-    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_panel_kernel<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(tridiag_panel_kernel<false>, dim3((unsigned)nb), dim3(PN_THREADS), lds, st, ws.Mbuf, ws.dT, ws.eT,
-                       ws.Tfac, (unsigned long long *)nullptr);
-    ADMM_HIP(hipGetLastError());
-    return ADMMNET_OK;
+    int rc = pn_launch_stage<16, true, false>(nb, ws, split ? 8 : 16, nullptr, st);
+    if (rc == ADMMNET_OK && split) rc = pn_launch_stage<8, false, false>(nb, ws, 8, nullptr, st);
+    return rc;
 }
 
 }  // namespace admmnet
