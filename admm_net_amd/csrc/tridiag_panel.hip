@@ -16,9 +16,22 @@
 //         y_I += T_IJ v_J      (row form: per-lane products, ONE 16-lane DPP reduction per block row)
 //         y_J += T_IJ^H v_I    (column form: per-lane sums over the 4 rows a lane holds + a 4-group reduction)
 //   * V, W panels (2 x 36 KB), the column / reflector vectors and the partial sums live in LDS.
-// Five barriers per reflector (column -> norm -> reflector -> matrix-vector product -> dot) instead of the rank-2
-// update's register sweep per reflector of tridiag_big.hip; outputs (d, e, reflector rows, taus) in that kernel's
-// format, so ungtr_big_kernel / the D&C / the back-transform are unchanged consumers.
+// Four barriers per reflector:
+//     F+B  w of the previous reflector; the column (looked ahead, see below) + that reflector's term, norm partials
+//     C    reflector scalars (branch-free, so the panel dots W^H v, V^H v -- taken over x below the unit row, which is
+//          known one phase before v -- run in the shadow of their dependent chain)
+//     D    y = M v from the register tiles; the unit row's term of the panel dots
+//     E    row waves: y - V g1 - W g2, p = tau y, p^H v;  the waves that hold no rows meanwhile bring the NEXT column up
+//          to date with the reflectors 0 .. j-1 (look-ahead) and append column j of the block reflector's T factor
+// instead of the rank-2 update's register sweep per reflector of tridiag_big.hip; outputs (d, e, reflector rows, taus)
+// in that kernel's format, so ungtr_big_kernel / the D&C / the back-transform are unchanged consumers.
+//   * Every phase is a latency chain (LDS round trip -> ~100 dependent instructions -> lane reduction -> LDS -> barrier),
+//     ~9 k cycles per reflector however small the trailing matrix is, and the register-resident half of the 256 x 256
+//     matrix admits one workgroup per CU.  So the reduction runs in three STAGES (one kernel template): panels 0..7 on
+//     8 waves (one matrix per CU), panels 8..11 on the trailing 128 x 128 matrix with 4 waves (69 KB of LDS: two
+//     matrices per CU), panels 12..15 on the trailing 64 x 64 with 2 waves (four per CU); the trailing tiles travel
+//     between the stages in the accumulator layout itself (Ws::Tail, 74 KB per matrix).  ADMMNET_PN_SPLIT=0 | 8 select
+//     one or two stages for A/B runs.
 //
 // Index conventions (arrow-first order, as every tridiagonalisation here): F = [[corner, a^H], [a, M]], M is D x D.
 // Reflector u (0 <= u < D) has its unit position at M-row u, annihilates F column u below it (for u >= 1 that is
@@ -48,6 +61,9 @@ struct PnShared {
     float2 Ap[DL][PN_PITCH];       // block column p of the panel-start matrix (the 16 columns the panel reduces)
     float2 colbuf[DL];             // the arrow: column of the prologue reflector
     float2 vbuf[DL];               // current reflector (zero above its unit position)
+    float2 xbuf[DL];               // ... with its unit entry zeroed (known one phase earlier: the panel dots start from it)
+    float2 hu;                     // the unit entry
+    float2 xnext[DL];              // the NEXT column, brought up to date with all panel reflectors but the current one
     float2 yrow[DL];               // row-form part of M v (written by the owner wave of each block row)
     float2 ycol[NW][DL];           // column-form partials per wave
     float2 g[32];                  // g[jj] = W_jj^H v, g[16 + jj] = V_jj^H v
@@ -119,6 +135,28 @@ __device__ __forceinline__ float2 pn_fms_c(float2 acc, float2 a, float2 b) {    
     acc.x = fmaf(-a.x, b.x, fmaf(a.y, b.y, acc.x));
     acc.y = fmaf(-a.x, b.y, fmaf(-a.y, b.x, acc.y));
     return acc;
+}
+
+// householder_c (eig_core.h) without branches, so that the scheduler can run its dependent chain in the shadow of other
+// work of the same basic block: same arithmetic in the normal range (q2 rsqrt(q2) with one Newton step), power-of-two
+// pre / post scaling instead of the exact-sqrt fallback outside it, the H = I case by selects at the end.
+__device__ __forceinline__ void pn_householder(float ar, float ai, float xnorm2, float &beta, float &tr, float &ti,
+                                               float &sr, float &si) {
+    const bool ident = (xnorm2 == 0.f && ai == 0.f);
+    const float q2 = ar * ar + ai * ai + xnorm2;
+    const float sc = (q2 < 1e-30f) ? 0x1p+64f : ((q2 > 1e30f) ? 0x1p-64f : 1.0f);
+    const float ps = (q2 < 1e-30f) ? 0x1p-32f : ((q2 > 1e30f) ? 0x1p+32f : 1.0f);
+    const float q2s = ident ? 1.0f : q2 * sc;
+    const float nrm = q2s * rsqrt_nr1(q2s) * ps;
+    const float b = -sign_of(nrm, ar);
+    const float ib = recip_nr(b);
+    const float dr = ar - b, di = ai;
+    const float iden = recip_nr(dr * dr + di * di);
+    beta = ident ? ar : b;
+    tr = ident ? 0.f : (b - ar) * ib;
+    ti = ident ? 0.f : -ai * ib;
+    sr = ident ? 0.f : dr * iden;
+    si = ident ? 0.f : -di * iden;
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -258,12 +296,44 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
     // date without waiting for the panel stores of the previous step (no barrier between the steps).
     float2 xcol = make_float2(0.f, 0.f), vreg = make_float2(0.f, 0.f), wreg = make_float2(0.f, 0.f),
            preg = make_float2(0.f, 0.f), hu = make_float2(0.f, 0.f), wu = make_float2(0.f, 0.f);
-    unsigned long long tmark = TIMING ? __builtin_amdgcn_s_memtime() : 0ull, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tmark = TIMING ? __builtin_amdgcn_s_memtime() : 0ull, tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto mark = [&](int id) {
         if constexpr (TIMING) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             tacc[id] += t - tmark;
             tmark = t;
+        }
+    };
+
+    // Look-ahead, on the waves that hold no rows (idle while the row waves assemble y): column j + 1 of the panel with the
+    // corrections of the reflectors 0 .. j - 1, so that the next step's column phase only adds reflector j's term (from
+    // registers).  x = A[:, j+1] - sum_k V[:, k] conj(W[c+1][k]) + W[:, k] conj(V[c+1][k]), rows >= c + 1.
+    auto lookahead = [&](int p, int j) {
+        if (tid >= DL && p >= 0 && j + 1 < 16) {   // (uniform per wave)
+            const int r2 = tid - DL, c2 = 16 * p + j + 1;
+            float2 x = sh.Ap[r2][j + 1];
+            if (r2 >= c2) {
+                for (int j0 = 0; j0 < j; j0 += 4) {   // four columns per pass: all 16 loads in flight together
+                    float2 vr[4], wr[4], vc[4], wc[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        vr[q] = sh.Vp[r2][j0 + q];
+                        wr[q] = sh.Wp[r2][j0 + q];
+                        vc[q] = sh.Vp[c2][j0 + q];
+                        wc[q] = sh.Wp[c2][j0 + q];
+                    }
+                    float2 t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool on = j0 + q < j;
+                        const float2 a = cmulc(vr[q], wc[q]), b2 = cmulc(wr[q], vc[q]);
+                        t[q] = on ? make_float2(a.x + b2.x, a.y + b2.y) : make_float2(0.f, 0.f);
+                    }
+                    x.x -= (t[0].x + t[1].x) + (t[2].x + t[3].x);
+                    x.y -= (t[0].y + t[1].y) + (t[2].y + t[3].y);
+                }
+            }
+            sh.xnext[r2] = x;
         }
     };
 
@@ -283,35 +353,18 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
             }
             // ---- B: bring the column up to date with the panel's earlier reflectors; d, alpha, |x|^2
             if (tid < DL) {
-                float2 x = (p >= 0) ? sh.Ap[r][j] : sh.colbuf[r];
-                if (r >= c && p >= 0 && j > 0) {
-                    for (int j0 = 0; j0 < j - 1; j0 += 4) {   // four columns per pass: all 16 loads in flight together
-                        float2 vr[4], wr[4], vc[4], wc[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            vr[q] = sh.Vp[r][j0 + q];
-                            wr[q] = sh.Wp[r][j0 + q];
-                            vc[q] = sh.Vp[c][j0 + q];
-                            wc[q] = sh.Wp[c][j0 + q];
-                        }
-                        // eight independent products, tree sum: the serial form was a 16-deep dependent fma chain per pass
-                        float2 t[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const bool on = j0 + q < j - 1;
-                            const float2 a = cmulc(vr[q], wc[q]), b2 = cmulc(wr[q], vc[q]);
-                            t[q] = on ? make_float2(a.x + b2.x, a.y + b2.y) : make_float2(0.f, 0.f);
-                        }
-                        x.x -= (t[0].x + t[1].x) + (t[2].x + t[3].x);
-                        x.y -= (t[0].y + t[1].y) + (t[2].y + t[3].y);
-                    }
-                    {
-                        const float2 a = cmulc(vreg, wu), b2 = cmulc(wreg, hu);   // column j - 1 from registers:
-                        x.x -= a.x + b2.x;                                        // (V, W)[c][j - 1] = (hu, wu)
-                        x.y -= a.y + b2.y;
-                    }
+                float2 x = (p >= 0) ? (j > 0 ? sh.xnext[r] : sh.Ap[r][j]) : sh.colbuf[r];
+                if (r >= c && p >= 0 && j > 0) {   // reflector j - 1 from registers: (V, W)[c][j - 1] = (hu, wu)
+                    const float2 a = cmulc(vreg, wu), b2 = cmulc(wreg, hu);
+                    x.x -= a.x + b2.x;
+                    x.y -= a.y + b2.y;
                 }
                 xcol = x;
+                {   // everything of the reflector but its unit entry is known here already
+                    const float2 xm = (r > u) ? x : make_float2(0.f, 0.f);
+                    sh.vbuf[r] = xm;
+                    sh.xbuf[r] = xm;
+                }
                 if (r == c) sh.dbuf[u] = x.x;
                 if (HEAD && p < 0 && r == 0) sh.dbuf[0] = corner;
                 if (r == u) sh.alpha = x;
@@ -322,29 +375,58 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
             if (u >= DL) break;        // c = DL - 1: only d[D] was due (uniform)
             mark(0);
             __syncthreads();   // (B2)
-            // ---- C: the reflector (scalars on the row waves only: the other four need no tau, just the H = I flag)
+            mark(8);
+            // ---- C: the reflector scalars -- a ~25-deep dependent chain (rsq, rcp, Newton steps) -- and, in the same
+            //      instruction stream so that they fill its latency slots, the panel dots W^H v, V^H v taken over
+            //      the rows below the unit position (xbuf); the unit row's term  conj(X[u][jj]) hu  is added in phase D.
+            //      dot id q = q0 + 4 wave + g : q < 16 -> W_q^H v, else V_{q-16}^H v; the 16 lanes of a group stride the
+            //      rows (x is zero above, so all row blocks are summed: fixed trip count, all loads in flight together)
             float2 tau = make_float2(0.f, 0.f);
-            if (wave < RW) {   // (uniform)
+            {
                 float xn2;
                 if constexpr (RW == 4) xn2 = (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
                 else if constexpr (RW == 2) xn2 = sh.red[0] + sh.red[1];
+                else if constexpr (RW == 1) xn2 = sh.red[0];
                 else xn2 = sh.red[0] + sh.red[1] + sh.red[2];
                 const float2 alpha = sh.alpha;
                 float beta, tre, tim, sr, si;
-                householder_c(alpha.x, alpha.y, xn2, beta, tre, tim, sr, si);
+                pn_householder(alpha.x, alpha.y, xn2, beta, tre, tim, sr, si);
+                float2 dacc[(32 + 4 * NW - 1) / (4 * NW)];
+#pragma unroll
+                for (int q0 = 0, ps = 0; q0 < 32; q0 += 4 * NW, ++ps) {   // (one pass with eight waves)
+                    const int q = (q0 + 4 * wave + g) & 31, jj = q & 15;
+                    float2 acc = make_float2(0.f, 0.f), acc2 = make_float2(0.f, 0.f);
+                    const float2(*X)[PN_PITCH] = (q < 16) ? sh.Wp : sh.Vp;
+#pragma unroll
+                    for (int i = 0; i < NT; i += 2) {
+                        acc = cmacc(acc, X[16 * i + c16][jj], sh.xbuf[16 * i + c16]);
+                        acc2 = cmacc(acc2, X[16 * i + 16 + c16][jj], sh.xbuf[16 * i + 16 + c16]);
+                    }
+                    dacc[ps] = make_float2(acc.x + acc2.x, acc.y + acc2.y);
+                }
                 const float g2 = sr * sr + si * si;
                 tau = make_float2(tre * g2, tim * g2);   // unnormalised reflector: H = I - tau v v^H, v = (alpha - beta, x)
                 hu = make_float2(alpha.x - beta, alpha.y);
-                vreg = (r == u) ? hu : (r > u ? xcol : make_float2(0.f, 0.f));
-                sh.vbuf[r] = vreg;
+                if (tid < DL) {
+                    vreg = (r == u) ? hu : (r > u ? xcol : make_float2(0.f, 0.f));
+                    if (r == u) sh.vbuf[r] = hu;
+                }
                 if (tid == 0) {
                     sh.ebuf[u] = beta;
                     sh.taubuf[u] = tau;
+                    sh.hu = hu;
                     sh.skip = (tre == 0.f && tim == 0.f) ? 1 : 0;
+                }
+#pragma unroll
+                for (int q0 = 0, ps = 0; q0 < 32; q0 += 4 * NW, ++ps) {
+                    const int qq = q0 + 4 * wave + g, jj = qq & 15;
+                    const float sx = pn_row16_sum(dacc[ps].x), sy = pn_row16_sum(dacc[ps].y);
+                    if (c16 == 0 && qq < 32 && jj < j && p >= 0) sh.g[qq] = make_float2(sx, sy);
                 }
             }
             mark(1);
             __syncthreads();   // (B3)
+            mark(9);
             if (__builtin_amdgcn_readfirstlane(sh.skip)) {        // H = I (uniform): v = 0, w = 0
                 hu = make_float2(0.f, 0.f);
                 wu = make_float2(0.f, 0.f);
@@ -354,6 +436,8 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                     sh.Wp[r][j] = make_float2(0.f, 0.f);
                 }
                 if (tid < 16) sh.Tl[tid][j] = make_float2(0.f, 0.f);
+                lookahead(p, j);
+                __syncthreads();
                 continue;
             }
             // ---- D: y = M v with the resident half (+ the panel dots W^H v, V^H v)
@@ -427,46 +511,37 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                     }
                 }
                 mark(3);
-                // panel dots: dot id q = 4 wave + g : q < 16 -> W_q^H v, else V_{q-16}^H v; the 16 lanes of a group
-                // stride the rows (v is zero above its unit row, so all sixteen 16-row blocks are summed: fixed trip
-                // count, all loads in flight together)
-#pragma unroll
-                for (int q0 = 0; q0 < 32; q0 += 4 * NW) {   // (one pass with eight waves)
-                    const int qw = q0 + 4 * wave;           // (uniform) first of this wave's four dots of the pass
-                    if (p >= 0 && qw < 32 && (qw & 15) < j) {   // (uniform) at least one of the four columns exists
-                        const int q = qw + g, jj = q & 15;
-                        float2 acc = make_float2(0.f, 0.f), acc2 = make_float2(0.f, 0.f);
-                        const float2(*X)[PN_PITCH] = (q < 16) ? sh.Wp : sh.Vp;
-#pragma unroll
-                        for (int i = 0; i < NT; i += 2) {
-                            acc = cmacc(acc, X[16 * i + c16][jj], sh.vbuf[16 * i + c16]);
-                            acc2 = cmacc(acc2, X[16 * i + 16 + c16][jj], sh.vbuf[16 * i + 16 + c16]);
-                        }
-                        acc.x = pn_row16_sum(acc.x + acc2.x);
-                        acc.y = pn_row16_sum(acc.y + acc2.y);
-                        if (c16 == 0 && jj < j) {
-                            sh.g[q] = acc;
-                            if (q >= 16) sh.Gp[jj][j] = acc;   // V_jj^H v_j: kept for the block reflector's T factor
-                        }
+                // the unit row's term of the panel dots (wave NW - 1 has the fewest tiles); Gp keeps V_jj^H v_j for the T factor
+                if (wave == NW - 1 && lane < 32 && p >= 0) {
+                    const int jj = lane & 15;
+                    const float2(*X)[PN_PITCH] = (lane < 16) ? sh.Wp : sh.Vp;
+                    const float2 t = cmacc(sh.g[lane], X[u][jj], sh.hu);
+                    if (jj < j) {
+                        sh.g[lane] = t;
+                        if (lane >= 16) sh.Gp[jj][j] = t;
                     }
                 }
             }
             mark(4);
             __syncthreads();   // (B4)
-            // ---- E: assemble y, corrections, p = tau y, p^H v
-            //      Meanwhile wave 7 (idle here, like waves 4 .. 6) appends column j to the panel's T factor (LAPACK clarft,
-            //      forward / columnwise):  T[j][j] = tau_j,  T[0:j, j] = -tau_j T[0:j, 0:j] (Y[:, 0:j]^H y_j) -- the Gram
-            //      entries are the panel dots the matrix-vector phase has just left in Gp.  Lane m = row m of T.
-            if (wave == NW - 1 && lane < 16 && p >= 0) {
+            mark(10);
+            // ---- E: assemble y, corrections, p = tau y, p^H v  (row waves; the others look ahead, see above)
+            lookahead(p, j);
+            //      ... and append column j to the panel's T factor (LAPACK clarft, forward /
+            //      columnwise):  T[j][j] = tau_j,  T[0:j, j] = -tau_j T[0:j, 0:j] (Y[:, 0:j]^H y_j) -- the Gram entries are the
+            //      panel dots left in Gp.  Lane group g = row m of T (four rows per wave and pass), lane c16 = term k.
+            if (wave >= RW && p >= 0) {   // (uniform)
                 const float2 gam = sh.taubuf[u];
-                float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
-                for (int k = 0; k < 15; ++k) {
-                    const float2 tk = sh.Tl[lane][k], gk = sh.Gp[k][j];
-                    if (k >= lane && k < j) acc = pn_fma_c(acc, tk, gk);
+                for (int ps = 0; ps < 4 / RW; ++ps) {
+                    const int m = 4 * ((wave - RW) + RW * ps) + g, k = c16;
+                    const float2 tk = sh.Tl[m][k], gk = sh.Gp[k][j];
+                    float2 acc = (k >= m && k < j) ? cmul(tk, gk) : make_float2(0.f, 0.f);
+                    acc.x = pn_row16_sum(acc.x);
+                    acc.y = pn_row16_sum(acc.y);
+                    const float2 t = cmul(gam, acc);
+                    if (c16 == 0) sh.Tl[m][j] = (m == j) ? gam : (m < j ? make_float2(-t.x, -t.y) : make_float2(0.f, 0.f));
                 }
-                const float2 t = cmul(gam, acc);
-                sh.Tl[lane][j] = (lane == j) ? gam : (lane < j ? make_float2(-t.x, -t.y) : make_float2(0.f, 0.f));
             }
             if (tid < DL) {
                 float2 y = make_float2(0.f, 0.f);
@@ -517,6 +592,7 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
             }
             mark(5);
             __syncthreads();   // (B5)
+            mark(11);
             // ---- F: w = p - (tau / 2)(p^H v) v ; store the panel column (read again only behind later barriers)
             {
                 float2 dot = sh.red2[0];
@@ -535,7 +611,6 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                     sh.Wp[r][j] = wreg;
                 }
             }
-            mark(6);
         }
         __syncthreads();
         // the panel's reflectors (rows u = 16 p + 1 + jj of the image, the layout the Q kernel reads) leave in one go
@@ -644,8 +719,8 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
         __syncthreads();   // the next panel's columns (Ap) are complete; Vp / Wp may be rewritten
     }
     if constexpr (TIMING) {
-        if (tid == 0)
-            for (int i = 0; i < 8; ++i) atomicAdd(&tdbg[i], tacc[i]);
+        if (lane == 0)
+            for (int i = 0; i < 12; ++i) atomicAdd(&tdbg[12 * wave + i], tacc[i]);
     }
     __syncthreads();
     // d, e, taus of the columns this stage reduced: local indices (HEAD: 0, else 1) .. min(16 pstop, DL)
@@ -668,7 +743,7 @@ static int pn_split() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("ADMMNET_PN_SPLIT");
-        v = (e && !strcmp(e, "0")) ? 0 : 8;
+        v = (e && !strcmp(e, "0")) ? 0 : (e && !strcmp(e, "8")) ? 8 : 84;
     }
     return v;
 }
@@ -689,27 +764,39 @@ int launch_tridiag_panel(int D, int64_t nb, const Ws &ws, hipStream_t st) {
         set_error("tridiag_panel: D=%d unsupported (256 only)", D);
         return ADMMNET_E_ARG;
     }
-    const bool split = pn_split() == 8 && ws.Tail != nullptr;
+    const bool split = pn_split() != 0 && ws.Tail != nullptr, split3 = split && pn_split() == 84;
     static const bool timing = getenv("ADMMNET_PN_TIMING") != nullptr;   // developer aid, never on by default
     if (timing) {
-        unsigned long long *ptime = nullptr, hb[16];
+        unsigned long long *ptime = nullptr, hb[3 * 96];
         ADMM_HIP(hipMalloc(&ptime, sizeof(hb)));
         ADMM_HIP(hipMemsetAsync(ptime, 0, sizeof(hb), st));
         int rc = pn_launch_stage<16, true, true>(nb, ws, split ? 8 : 16, ptime, st);
-        if (rc == ADMMNET_OK && split) rc = pn_launch_stage<8, false, true>(nb, ws, 8, ptime + 8, st);
+        if (rc == ADMMNET_OK && split) rc = pn_launch_stage<8, false, true>(nb, ws, split3 ? 4 : 8, ptime + 96, st);
+        if (rc == ADMMNET_OK && split3) rc = pn_launch_stage<4, false, true>(nb, ws, 4, ptime + 192, st);
         if (rc != ADMMNET_OK) return rc;
         ADMM_HIP(hipMemcpyAsync(hb, ptime, sizeof(hb), hipMemcpyDeviceToHost, st));
         ADMM_HIP(hipStreamSynchronize(st));
         ADMM_HIP(hipFree(ptime));
-        static const char *nm[8] = {"column+norm", "reflector", "matvec tiles", "row flush", "panel dots", "assemble+dot", "w+store", "mfma update"};
-        fprintf(stderr, "[tridiag_panel timing] nb=%lld  mean cycles per matrix (wave 0, barrier waits fall into the NEXT phase), stage 1 | stage 2:\n",
-                (long long)nb);
-        for (int i = 0; i < 8; ++i)
-            fprintf(stderr, "   %-14s %10.0f %10.0f\n", nm[i], (double)hb[i] / (double)nb, (double)hb[8 + i] / (double)nb);
+        static const char *nm[12] = {"w+T | column+norm", "reflector+dots", "matvec tiles", "row flush", "dot fix-up", "assemble | look-ahead", "(w+store)", "panel end + mfma",
+                                     "wait B2", "wait B3", "wait B4", "wait B5"};
+        static const int order[12] = {0, 8, 1, 9, 2, 3, 4, 10, 5, 11, 6, 7};
+        fprintf(stderr, "[tridiag_panel timing] nb=%lld  mean kilocycles per matrix and wave\n", (long long)nb);
+        for (int stg = 0; stg < 3; ++stg) {
+            const int nw = stg == 0 ? 8 : (stg == 1 ? 4 : 2);
+            if ((stg == 1 && !split) || (stg == 2 && !split3)) continue;
+            fprintf(stderr, " stage %d\n", stg + 1);
+            for (int ii = 0; ii < 12; ++ii) {
+                const int i = order[ii];
+                fprintf(stderr, "   %-22s", nm[i]);
+                for (int w = 0; w < nw; ++w) fprintf(stderr, " %8.1f", (double)hb[96 * stg + 12 * w + i] / (double)nb / 1e3);
+                fprintf(stderr, "\n");
+            }
+        }
         return ADMMNET_OK;
     }
     int rc = pn_launch_stage<16, true, false>(nb, ws, split ? 8 : 16, nullptr, st);
-    if (rc == ADMMNET_OK && split) rc = pn_launch_stage<8, false, false>(nb, ws, 8, nullptr, st);
+    if (rc == ADMMNET_OK && split) rc = pn_launch_stage<8, false, false>(nb, ws, split3 ? 4 : 8, nullptr, st);
+    if (rc == ADMMNET_OK && split3) rc = pn_launch_stage<4, false, false>(nb, ws, 4, nullptr, st);
     return rc;
 }
 

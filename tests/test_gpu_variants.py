@@ -41,6 +41,8 @@ VARIANTS = {
     "full_storage": {"ADMMNET_LEAN": "0"},
     "sweep_big": {"ADMMNET_TRIDIAG_BIG": "sweep"},     # D = 256: per-reflector register sweep + explicit Q + Q W
     "explicit_q": {"ADMMNET_BACK": "q"},               # D = 256: panel tridiagonalisation, explicit Q + Q W
+    "panel_one_stage": {"ADMMNET_PN_SPLIT": "0"},      # D = 256: the whole panel reduction in the 8-wave kernel
+    "panel_two_stages": {"ADMMNET_PN_SPLIT": "8"},     # D = 256: panels 0..7 | 8..15 (default: 0..7 | 8..11 | 12..15)
 }
 
 
