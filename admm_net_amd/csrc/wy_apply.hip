@@ -13,11 +13,14 @@
 //   Zt = T Z      Z, just produced as an accumulator tile, is the B operand again
 //   X -= Y Zt     Zt as B operand, Y rows as A operands, accumulated straight into the X tiles
 // so no X / Z / Zt element ever moves between lanes or through memory.  A workgroup = 4 waves = 64 columns shares the
-// panel (Y: 256 x 16 complex = 36 KB with padding, T: 2 KB) through LDS; 5 workgroups per matrix cover the 257 columns.
+// panel (Y: 256 x 16 complex = 36 KB with padding, T: 2 KB) through LDS; 4 workgroups per matrix cover columns 0 .. 255.
+// The 257th eigenvector would cost a fifth workgroup with one live wave and 1 / 16 live columns in it (measured: 18 %
+// of the kernel); wy_lastcol_kernel applies the 256 reflectors to that one vector directly, one wave per matrix.
 #include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
+#include "lane_reduce.h"
 
 namespace admmnet {
 
@@ -41,10 +44,9 @@ __global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g = lane >> 4;
-    const int64_t bm = blockIdx.y;                 // (the five column slabs of a matrix are neighbours in the grid: they
+    const int64_t bm = blockIdx.y;                 // (the four column slabs of a matrix are neighbours in the grid: they
     const int cb = 4 * blockIdx.x + wave;          //  read the same reflectors at about the same time)
                                                    // column block of this wave: eigenvectors 16 cb .. 16 cb + 15
-    const bool live = 16 * cb < n;                 // (uniform) the last workgroup has one live wave (column 256)
     const int col = 16 * cb + c16;
     const float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
     const float2 *Tg = Tfac + bm * 17 * 256;
@@ -55,12 +57,8 @@ __global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *_
     f32x4 xr[16], xi[16];
 #pragma unroll
     for (int I = 0; I < 16; ++I) {
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (live && col < n) {
-            const float *src = WT + (int64_t)col * n + 1 + 16 * I + 4 * g;
-            v = f32x4{src[0], src[1], src[2], src[3]};
-        }
-        xr[I] = v;
+        const float *src = WT + (int64_t)col * n + 1 + 16 * I + 4 * g;
+        xr[I] = f32x4{src[0], src[1], src[2], src[3]};
         xi[I] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
@@ -87,7 +85,6 @@ __global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *_
         sh.T[tid >> 4][tid & 15] = tpre;
         __syncthreads();
         if (pp > 0) gload(pp - 1);
-        if (!live) continue;                       // (uniform per wave; the barriers above are outside)
         // ---- Z = Y^H X  (16 reflectors x 16 columns):  Zr = Yr Xr + Yi Xi,  Zi = Yr Xi - Yi Xr
         //      (Splitting this 256-term accumulation into block-local sums added pairwise was tried for accuracy: the
         //      distance of V to the float64 back-transform of the same reflectors moved from 9.3e-7 to 8.7e-7 only, for
@@ -144,13 +141,72 @@ __global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *_
         }
     }
     // ---- V^T image for the rebuild: VT[c][rho] = Re V[rho][c], VT[c][D + rho] = Im V[rho][c]  (pitch 2 D)
-    if (live && col < n) {
+    {
         float *dst = Vb + (int64_t)col * 2 * D + 4 * g;
 #pragma unroll
         for (int I = 0; I < 16; ++I) {
             *reinterpret_cast<float4 *>(dst + 16 * I) = make_float4(xr[I].x, xr[I].y, xr[I].z, xr[I].w);
             *reinterpret_cast<float4 *>(dst + D + 16 * I) = make_float4(xi[I].x, xi[I].y, xi[I].z, xi[I].w);
         }
+    }
+}
+
+// Column 256 of V: x <- H_0 H_1 ... H_{D-1} x, reflector by reflector (H_u = I - tau_u v_u v_u^H, v_u = image row u, zero
+// above its unit row; taus in the consumed arrow slot).  One wave per matrix, lane l holds rows l, l + 64, l + 128, l + 192
+// (the layout of a coalesced row load); eight reflectors per batch, the next batch's loads in flight behind the current
+// batch's dot -> wave sum -> update chains.
+constexpr int WL_BATCH = 8;
+
+__global__ __launch_bounds__(64) void wy_lastcol_kernel(const float2 *__restrict__ Mbuf, const float *__restrict__ Wbuf,
+                                                        int64_t wt_off, float *__restrict__ VT) {
+    constexpr int D = WY_D, n = D + 1;
+    const int lane = threadIdx.x;
+    const int64_t bm = blockIdx.x;
+    const float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
+    const float2 *taus = Mg + (int64_t)D * D;
+    const float *WT = Wbuf + bm * (int64_t)3 * n * n + wt_off;   // WT[c][i] = W[i][c]
+    float *Vb = VT + bm * ((int64_t)n * 2 * D);
+    float2 x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = make_float2(WT[(int64_t)D * n + 1 + lane + 64 * k], 0.f);
+    float2 va[WL_BATCH][4], vb[WL_BATCH][4], ta[WL_BATCH], tb[WL_BATCH];
+    auto gload = [&](float2(&buf)[WL_BATCH][4], float2(&tt)[WL_BATCH], int u0) {   // reflectors u0, u0 - 1, ...
+#pragma unroll
+        for (int i = 0; i < WL_BATCH; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)   // (uniform test: v_u is zero above row u -- half of the image is never read)
+                buf[i][k] = (64 * k + 63 >= u0 - i) ? Mg[(int64_t)(u0 - i) * D + lane + 64 * k] : make_float2(0.f, 0.f);
+            tt[i] = taus[u0 - i];
+        }
+    };
+    auto apply = [&](const float2(&buf)[WL_BATCH][4], const float2(&tt)[WL_BATCH]) {
+#pragma unroll
+        for (int i = 0; i < WL_BATCH; ++i) {
+            float2 d0 = cmacc(make_float2(0.f, 0.f), buf[i][0], x[0]), d1 = cmacc(make_float2(0.f, 0.f), buf[i][1], x[1]);
+            d0 = cmacc(d0, buf[i][2], x[2]);
+            d1 = cmacc(d1, buf[i][3], x[3]);
+            float dx = pn_row16_sum(d0.x + d1.x), dy = pn_row16_sum(d0.y + d1.y);
+            pn_group_sum2(dx, dy);
+            const float2 sc = cmul(tt[i], make_float2(dx, dy));   // tau (v^H x)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                x[k].x -= sc.x * buf[i][k].x - sc.y * buf[i][k].y;
+                x[k].y -= sc.x * buf[i][k].y + sc.y * buf[i][k].x;
+            }
+        }
+    };
+    gload(va, ta, D - 1);
+    for (int b = 0; b < D / WL_BATCH; b += 2) {
+        gload(vb, tb, D - 1 - WL_BATCH * (b + 1));
+        apply(va, ta);
+        if (b + 2 < D / WL_BATCH) gload(va, ta, D - 1 - WL_BATCH * (b + 2));
+        apply(vb, tb);
+    }
+    float *dst = Vb + (int64_t)D * 2 * D;   // row c = 256 of the V^T image
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        dst[lane + 64 * k] = x[k].x;
+        dst[D + lane + 64 * k] = x[k].y;
     }
 }
 
@@ -172,8 +228,10 @@ int launch_wy_apply(int D, int64_t nb, const Ws &ws, hipStream_t st) {
         return ADMMNET_E_ARG;
     }
     const int n = D + 1;
-    hipLaunchKernelGGL(wy_apply_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)nb), dim3(WY_THREADS), 0, st, ws.Mbuf,
-                       ws.Tfac, ws.Wdc, dc_final_offset(n), ws.VT);
+    hipLaunchKernelGGL(wy_apply_kernel, dim3((unsigned)(D / 64), (unsigned)nb), dim3(WY_THREADS), 0, st, ws.Mbuf, ws.Tfac,
+                       ws.Wdc, dc_final_offset(n), ws.VT);
+    ADMM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(wy_lastcol_kernel, dim3((unsigned)nb), dim3(64), 0, st, ws.Mbuf, ws.Wdc, dc_final_offset(n), ws.VT);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }
