@@ -124,6 +124,25 @@ __device__ __forceinline__ void pn_householder(float ar, float ai, float xnorm2,
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+// Complex multiply-accumulate in TWO packed instructions (the scalar form takes four): v_pk_fma_f32 with op_sel picking
+// the real / imaginary half of each operand pair and neg_lo / neg_hi the sign -- the compiler folds the broadcast of the
+// first product but materialises the swapped, negated operand of the second (v_xor + v_mov), hence the asm.  The skinny
+// phases are bound by the VALU issue of ONE wave per SIMD (a wave64 instruction holds the 16-lane SIMD for 4 cycles).
+__device__ __forceinline__ v2f pk_cfma(v2f acc, v2f a, v2f b) {        // acc + a b
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "+v"(acc)
+        : "v"(a), "v"(b));
+    return acc;
+}
+__device__ __forceinline__ v2f pk_cfma_conj(v2f acc, v2f a, v2f b) {   // acc + conj(a) b
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
+        : "+v"(acc)
+        : "v"(a), "v"(b));
+    return acc;
+}
+__device__ __forceinline__ v2f pk2(float2 a) { return v2f{a.x, a.y}; }
 __device__ __forceinline__ v2f pn_lo(f32x4 a) { return v2f{a.x, a.y}; }
 __device__ __forceinline__ v2f pn_hi(f32x4 a) { return v2f{a.z, a.w}; }
 // one 16 x 16 tile (tre, tim: rows 4 g + q of column c16) in the matrix-vector product, packed FMAs over row pairs:
@@ -202,6 +221,7 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
     constexpr int D = PN_D, n = D + 1;
     constexpr int DL = 16 * NT, NW = NT / 2, RW = DL / 64, THREADS = 64 * NW;   // RW row waves, NW tile waves
     constexpr int R0 = D - DL, P0 = 16 - NT;                                    // first M-row / panel of this stage
+    constexpr bool ALLW = (NT == 16);   // every wave runs the reflector scalars (see phase C)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile ownership tests below are uniform branches
     const int c16_0 = lane & 15, g_0 = lane >> 4;
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
     // date without waiting for the panel stores of the previous step (no barrier between the steps).
     float2 xcol = make_float2(0.f, 0.f), vreg = make_float2(0.f, 0.f), wreg = make_float2(0.f, 0.f),
            preg = make_float2(0.f, 0.f), hu = make_float2(0.f, 0.f), wu = make_float2(0.f, 0.f);
-    unsigned long long tmark = TIMING ? __builtin_amdgcn_s_memtime() : 0ull, tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tmark = TIMING ? __builtin_amdgcn_s_memtime() : 0ull, tacc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto mark = [&](int id) {
         if constexpr (TIMING) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -277,8 +297,9 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
             const int r2 = tid - DL, c2 = 16 * p + j + 1;
             float2 x = sh.Ap[r2][j + 1];
             if (r2 >= c2) {
+                v2f acc = v2f{0.f, 0.f}, acc2 = v2f{0.f, 0.f};
                 for (int j0 = 0; j0 < j; j0 += 4) {   // four columns per pass: all 16 loads in flight together
-                    float2 vr[4], wr[4], vc[4], wc[4];
+                    float2 vr[4], wr[4], vc[4], wc[4];    // (columns >= j of the panel are zero: no masks)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         vr[q] = sh.Vp[r2][j0 + q];
@@ -286,22 +307,27 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                         vc[q] = sh.Vp[c2][j0 + q];
                         wc[q] = sh.Wp[c2][j0 + q];
                     }
-                    float2 t[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const bool on = j0 + q < j;
-                        const float2 a = cmulc(vr[q], wc[q]), b2 = cmulc(wr[q], vc[q]);
-                        t[q] = on ? make_float2(a.x + b2.x, a.y + b2.y) : make_float2(0.f, 0.f);
+                        acc = pk_cfma_conj(acc, pk2(wc[q]), pk2(vr[q]));     // v conj(w_c)
+                        acc2 = pk_cfma_conj(acc2, pk2(vc[q]), pk2(wr[q]));   // w conj(v_c)
                     }
-                    x.x -= (t[0].x + t[1].x) + (t[2].x + t[3].x);
-                    x.y -= (t[0].y + t[1].y) + (t[2].y + t[3].y);
                 }
+                x.x -= acc.x + acc2.x;
+                x.y -= acc.y + acc2.y;
             }
             sh.xnext[r2] = x;
         }
     };
 
     for (int p = HEAD ? -1 : 0; p < NT; ++p) {
+        if (p >= 0) {   // the panel's columns start from zero: the skinny sums below run over whole groups of four columns
+            for (int i = tid; i < DL * 16; i += THREADS) {
+                sh.Vp[i >> 4][i & 15] = make_float2(0.f, 0.f);
+                sh.Wp[i >> 4][i & 15] = make_float2(0.f, 0.f);
+            }
+            if (tid < 32) sh.g[tid] = make_float2(0.f, 0.f);
+        }
         for (int j = (p < 0) ? 15 : 0; j < 16; ++j) {
             const int c = 16 * p + j, u = c + 1;
             // the lane coordinates are re-derived per step from an opaque copy: otherwise every LDS address of the
@@ -319,9 +345,10 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
             if (tid < DL) {
                 float2 x = (p >= 0) ? (j > 0 ? sh.xnext[r] : sh.Ap[r][j]) : sh.colbuf[r];
                 if (r >= c && p >= 0 && j > 0) {   // reflector j - 1 from registers: (V, W)[c][j - 1] = (hu, wu)
-                    const float2 a = cmulc(vreg, wu), b2 = cmulc(wreg, hu);
-                    x.x -= a.x + b2.x;
-                    x.y -= a.y + b2.y;
+                    v2f a = pk_cfma_conj(v2f{0.f, 0.f}, pk2(wu), pk2(vreg));
+                    a = pk_cfma_conj(a, pk2(hu), pk2(wreg));
+                    x.x -= a.x;
+                    x.y -= a.y;
                 }
                 xcol = x;
                 {   // everything of the reflector but its unit entry is known here already
@@ -347,39 +374,48 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
             //      rows (x is zero above, so all row blocks are summed: fixed trip count, all loads in flight together)
             float2 tau = make_float2(0.f, 0.f);
             {
-                float xn2;
-                if constexpr (RW == 4) xn2 = (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
-                else if constexpr (RW == 2) xn2 = sh.red[0] + sh.red[1];
-                else if constexpr (RW == 1) xn2 = sh.red[0];
-                else xn2 = sh.red[0] + sh.red[1] + sh.red[2];
-                const float2 alpha = sh.alpha;
-                float beta, tre, tim, sr, si;
-                pn_householder(alpha.x, alpha.y, xn2, beta, tre, tim, sr, si);
                 float2 dacc[(32 + 4 * NW - 1) / (4 * NW)];
+                auto dots = [&]() {
 #pragma unroll
-                for (int q0 = 0, ps = 0; q0 < 32; q0 += 4 * NW, ++ps) {   // (one pass with eight waves)
-                    const int q = (q0 + 4 * wave + g) & 31, jj = q & 15;
-                    float2 acc = make_float2(0.f, 0.f), acc2 = make_float2(0.f, 0.f);
-                    const float2(*X)[PN_PITCH] = (q < 16) ? sh.Wp : sh.Vp;
+                    for (int q0 = 0, ps = 0; q0 < 32; q0 += 4 * NW, ++ps) {   // (one pass with eight waves)
+                        const int q = (q0 + 4 * wave + g) & 31, jj = q & 15;
+                        v2f acc = v2f{0.f, 0.f}, acc2 = v2f{0.f, 0.f};
+                        const float2(*X)[PN_PITCH] = (q < 16) ? sh.Wp : sh.Vp;
 #pragma unroll
-                    for (int i = 0; i < NT; i += 2) {
-                        acc = cmacc(acc, X[16 * i + c16][jj], sh.xbuf[16 * i + c16]);
-                        acc2 = cmacc(acc2, X[16 * i + 16 + c16][jj], sh.xbuf[16 * i + 16 + c16]);
+                        for (int i = 0; i < NT; i += 2) {
+                            acc = pk_cfma_conj(acc, pk2(X[16 * i + c16][jj]), pk2(sh.xbuf[16 * i + c16]));
+                            acc2 = pk_cfma_conj(acc2, pk2(X[16 * i + 16 + c16][jj]), pk2(sh.xbuf[16 * i + 16 + c16]));
+                        }
+                        dacc[ps] = make_float2(acc.x + acc2.x, acc.y + acc2.y);
                     }
-                    dacc[ps] = make_float2(acc.x + acc2.x, acc.y + acc2.y);
-                }
-                const float g2 = sr * sr + si * si;
-                tau = make_float2(tre * g2, tim * g2);   // unnormalised reflector: H = I - tau v v^H, v = (alpha - beta, x)
-                hu = make_float2(alpha.x - beta, alpha.y);
-                if (tid < DL) {
-                    vreg = (r == u) ? hu : (r > u ? xcol : make_float2(0.f, 0.f));
-                    if (r == u) sh.vbuf[r] = hu;
-                }
-                if (tid == 0) {
-                    sh.ebuf[u] = beta;
-                    sh.taubuf[u] = tau;
-                    sh.hu = hu;
-                    sh.skip = (tre == 0.f && tim == 0.f) ? 1 : 0;
+                };
+                // (the scalars are needed by the row waves only, and the others share their SIMDs; measured: skipping them
+                //  there gains 6 % in the 4-wave stage and LOSES 4 % in the 8-wave stage, which keeps the common path)
+                if (ALLW || wave < RW) {   // (uniform)
+                    float xn2;
+                    if constexpr (RW == 4) xn2 = (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
+                    else if constexpr (RW == 2) xn2 = sh.red[0] + sh.red[1];
+                    else if constexpr (RW == 1) xn2 = sh.red[0];
+                    else xn2 = sh.red[0] + sh.red[1] + sh.red[2];
+                    const float2 alpha = sh.alpha;
+                    float beta, tre, tim, sr, si;
+                    pn_householder(alpha.x, alpha.y, xn2, beta, tre, tim, sr, si);
+                    dots();
+                    const float g2 = sr * sr + si * si;
+                    tau = make_float2(tre * g2, tim * g2);   // unnormalised reflector: H = I - tau v v^H, v = (alpha - beta, x)
+                    hu = make_float2(alpha.x - beta, alpha.y);
+                    if (tid < DL) {
+                        vreg = (r == u) ? hu : (r > u ? xcol : make_float2(0.f, 0.f));
+                        if (r == u) sh.vbuf[r] = hu;
+                    }
+                    if (tid == 0) {
+                        sh.ebuf[u] = beta;
+                        sh.taubuf[u] = tau;
+                        sh.hu = hu;
+                        sh.skip = (tre == 0.f && tim == 0.f) ? 1 : 0;
+                    }
+                } else {
+                    dots();
                 }
 #pragma unroll
                 for (int q0 = 0, ps = 0; q0 < 32; q0 += 4 * NW, ++ps) {
@@ -523,9 +559,11 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                             y.y += t[w].y;
                         }
                     }
+                    mark(6);
                     if (p >= 0) {
+                        v2f acc = v2f{0.f, 0.f}, acc2 = v2f{0.f, 0.f};
                         for (int j0 = 0; j0 < j; j0 += 4) {
-                            float2 vr[4], wr[4], g1[4], g2[4];
+                            float2 vr[4], wr[4], g1[4], g2[4];   // (columns >= j of the panel and of g are zero)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 vr[q] = sh.Vp[r][j0 + q];
@@ -533,18 +571,17 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                                 g1[q] = sh.g[j0 + q];
                                 g2[q] = sh.g[16 + j0 + q];
                             }
-                            float2 t[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const bool on = j0 + q < j;
-                                const float2 a = cmul(vr[q], g1[q]), b2 = cmul(wr[q], g2[q]);
-                                t[q] = on ? make_float2(a.x + b2.x, a.y + b2.y) : make_float2(0.f, 0.f);
+                                acc = pk_cfma(acc, pk2(vr[q]), pk2(g1[q]));
+                                acc2 = pk_cfma(acc2, pk2(wr[q]), pk2(g2[q]));
                             }
-                            y.x -= (t[0].x + t[1].x) + (t[2].x + t[3].x);
-                            y.y -= (t[0].y + t[1].y) + (t[2].y + t[3].y);
                         }
+                        y.x -= acc.x + acc2.x;
+                        y.y -= acc.y + acc2.y;
                     }
                     y = cmul(tau, y);
+                    mark(12);
                 }
                 preg = y;
                 if (r == u) sh.pu = y;
@@ -558,7 +595,7 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
             __syncthreads();   // (B5)
             mark(11);
             // ---- F: w = p - (tau / 2)(p^H v) v ; store the panel column (read again only behind later barriers)
-            {
+            if (ALLW || wave < RW) {   // (uniform)
                 float2 dot = sh.red2[0];
 #pragma unroll
                 for (int q = 1; q < RW; ++q) {
@@ -684,7 +721,7 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
     }
     if constexpr (TIMING) {
         if (lane == 0)
-            for (int i = 0; i < 12; ++i) atomicAdd(&tdbg[12 * wave + i], tacc[i]);
+            for (int i = 0; i < 14; ++i) atomicAdd(&tdbg[14 * wave + i], tacc[i]);
     }
     __syncthreads();
     // d, e, taus of the columns this stage reduced: local indices (HEAD: 0, else 1) .. min(16 pstop, DL)
@@ -731,28 +768,28 @@ int launch_tridiag_panel(int D, int64_t nb, const Ws &ws, hipStream_t st) {
     const bool split = pn_split() != 0 && ws.Tail != nullptr, split3 = split && pn_split() == 84;
     static const bool timing = getenv("ADMMNET_PN_TIMING") != nullptr;   // developer aid, never on by default
     if (timing) {
-        unsigned long long *ptime = nullptr, hb[3 * 96];
+        unsigned long long *ptime = nullptr, hb[3 * 112];
         ADMM_HIP(hipMalloc(&ptime, sizeof(hb)));
         ADMM_HIP(hipMemsetAsync(ptime, 0, sizeof(hb), st));
         int rc = pn_launch_stage<16, true, true>(nb, ws, split ? 8 : 16, ptime, st);
-        if (rc == ADMMNET_OK && split) rc = pn_launch_stage<8, false, true>(nb, ws, split3 ? 4 : 8, ptime + 96, st);
-        if (rc == ADMMNET_OK && split3) rc = pn_launch_stage<4, false, true>(nb, ws, 4, ptime + 192, st);
+        if (rc == ADMMNET_OK && split) rc = pn_launch_stage<8, false, true>(nb, ws, split3 ? 4 : 8, ptime + 112, st);
+        if (rc == ADMMNET_OK && split3) rc = pn_launch_stage<4, false, true>(nb, ws, 4, ptime + 224, st);
         if (rc != ADMMNET_OK) return rc;
         ADMM_HIP(hipMemcpyAsync(hb, ptime, sizeof(hb), hipMemcpyDeviceToHost, st));
         ADMM_HIP(hipStreamSynchronize(st));
         ADMM_HIP(hipFree(ptime));
-        static const char *nm[12] = {"w+T | column+norm", "reflector+dots", "matvec tiles", "row flush", "dot fix-up", "assemble | look-ahead", "(w+store)", "panel end + mfma",
-                                     "wait B2", "wait B3", "wait B4", "wait B5"};
-        static const int order[12] = {0, 8, 1, 9, 2, 3, 4, 10, 5, 11, 6, 7};
+        static const char *nm[14] = {"w | column+norm", "reflector+dots", "matvec tiles", "row flush", "dot fix-up", "E: dot | look-ahead+T", "E: assemble y", "panel end + mfma",
+                                     "wait B2", "wait B3", "wait B4", "wait B5", "E: corrections", ""};
+        static const int order[13] = {0, 8, 1, 9, 2, 3, 4, 10, 6, 12, 5, 11, 7};
         fprintf(stderr, "[tridiag_panel timing] nb=%lld  mean kilocycles per matrix and wave\n", (long long)nb);
         for (int stg = 0; stg < 3; ++stg) {
             const int nw = stg == 0 ? 8 : (stg == 1 ? 4 : 2);
             if ((stg == 1 && !split) || (stg == 2 && !split3)) continue;
             fprintf(stderr, " stage %d\n", stg + 1);
-            for (int ii = 0; ii < 12; ++ii) {
+            for (int ii = 0; ii < 13; ++ii) {
                 const int i = order[ii];
                 fprintf(stderr, "   %-22s", nm[i]);
-                for (int w = 0; w < nw; ++w) fprintf(stderr, " %8.1f", (double)hb[96 * stg + 12 * w + i] / (double)nb / 1e3);
+                for (int w = 0; w < nw; ++w) fprintf(stderr, " %8.1f", (double)hb[112 * stg + 14 * w + i] / (double)nb / 1e3);
                 fprintf(stderr, "\n");
             }
         }
