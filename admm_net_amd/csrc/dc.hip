@@ -41,6 +41,7 @@ struct DcShared {
     int conf[DC_MAXLEAF];    // team scan: a rotation chain reached the next run -> serial scan for this merge
     int mx[DC_MAXLEAF][2];   // max |d|, max |z| of a merge as float bit patterns (non-negative: integer order)
     int fail;
+    int nrm;                 // max |d|, |e| of the whole matrix (float bits)
 };
 
 template <int OCC>
@@ -104,13 +105,16 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         for (int b = 0; b < nleaf; ++b) sh.bnd[0][b] = dc_leaf_start(n, nleaf, b);
         sh.bnd[0][nleaf] = n;
         sh.fail = 0;
+        sh.nrm = 0;
     }
     for (int i = tid; i < 2 * DC_MAXLEAF; i += DC_THREADS) (&sh.mx[0][0])[i] = 0;
     int bad = 0;
+    float amax = 0.f;
     for (int i = tid; i < n; i += DC_THREADS) {
         lam[i] = dg[i];
         e0[i] = (i < n - 1) ? eg[i] : 0.f;
         bad |= !(isfinite(lam[i]) && isfinite(e0[i]));
+        amax = fmaxf(amax, fmaxf(fabsf(lam[i]), fabsf(e0[i])));
     }
     // A non-finite tridiagonal (NaN / Inf in the input): report and leave.  torch.linalg.eigh raises on such input, and
     // the rank-by-counting / deflation bookkeeping below would leave permutation slots unwritten and index with them.
@@ -129,6 +133,27 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
     // both ping-pong buffers start at zero: every level writes only inside its diagonal blocks and
     // the next level reads the (zero) off-diagonal blocks of the pair it merges
     for (int64_t i = tid; i < (int64_t)2 * n * n; i += DC_THREADS) WA[i] = 0.f;
+    // LAPACK sstedc scales T to unit max-norm first (slascl): the deflation tests compare rho |z_j| (z normalised) with
+    // 8 eps max(|d|, |z|), which means "negligible against T" only on a matrix of norm ~ 1.  Scaled here by the power
+    // of two that brings max(|d|, |e|) into [0.5, 1) -- exact, so a matrix that already is of that size takes the very
+    // same arithmetic as before -- and the eigenvalues are scaled back on the way out.
+    atomicMax(&sh.nrm, __float_as_int(amax));
+    __syncthreads();
+    float unscale = 1.f;
+    {
+        const float orgnrm = __int_as_float(sh.nrm);
+        if (orgnrm > 0.f) {
+            int ex;
+            (void)frexpf(orgnrm, &ex);
+            ex = max(-120, min(120, ex));
+            const float sc = ldexpf(1.f, -ex);
+            unscale = ldexpf(1.f, ex);
+            for (int i = tid; i < n; i += DC_THREADS) {
+                lam[i] *= sc;
+                e0[i] *= sc;
+            }
+        }
+    }
     __syncthreads();
     mark(0);
     // tear: d[k-1] -= |e[k-1]|, d[k] -= |e[k-1]| at every leaf boundary k
@@ -479,7 +504,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
     //      transposed image itself (backrebuild.hip; dc_final_offset() tells it which ping-pong buffer) -- W
     //      row-major (W[i][j], j = eigenvalue) in the third region: the orientation vgemm_kernel reads coalesced
     for (int i = tid; i < n; i += DC_THREADS) {
-        wout[bm * n + i] = lam[i];
+        wout[bm * n + i] = lam[i] * unscale;
         w0out[bm * n + i] = Ws[(int64_t)i * n];
     }
     if (rowmajor) {

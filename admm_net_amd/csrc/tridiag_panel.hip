@@ -212,7 +212,7 @@ __device__ __forceinline__ int64_t pn_tail_at(int I, int J, int q, int lane) {
 template <int NT, bool HEAD, bool TIMING>
 __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__restrict__ Mbuf, float *__restrict__ dT,
                                                                    float *__restrict__ eT, float2 *__restrict__ Tfac,
-                                                                   float2 *__restrict__ Tail, int pstop,
+                                                                   float2 *__restrict__ Tail, int pstop, int zfill,
                                                                    unsigned long long *__restrict__ tdbg) {
     static_assert(NT % 4 == 0 && NT <= 16 && (HEAD == (NT == 16)), "stage geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -621,10 +621,12 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                 if (uu < DL) Mg[(int64_t)(R0 + uu) * D + R0 + tid] = sh.Vp[tid][jj];
             }
         }
-        if constexpr (!HEAD) {   // the reflectors are zero above this stage's rows
-            for (int i = tid; i < 16 * R0; i += THREADS) {
-                const int uu = 16 * p + 1 + i / R0;
-                if (uu < DL) Mg[(int64_t)(R0 + uu) * D + i % R0] = make_float2(0.f, 0.f);
+        if constexpr (!HEAD) {   // the reflectors are zero above this stage's rows: only the explicit-Q consumer
+            if (zfill) {         // (ADMMNET_BACK=q) reads there
+                for (int i = tid; i < 16 * R0; i += THREADS) {
+                    const int uu = 16 * p + 1 + i / R0;
+                    if (uu < DL) Mg[(int64_t)(R0 + uu) * D + i % R0] = make_float2(0.f, 0.f);
+                }
             }
         }
         // ... and the T factor of the panel's block reflector  H_u0 H_u0+1 ... = I - Y T Y^H  (built column by column
@@ -755,7 +757,7 @@ static int pn_launch_stage(int64_t nb, const Ws &ws, int pstop, unsigned long lo
     ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_panel_kernel<NT, HEAD, TIMING>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((tridiag_panel_kernel<NT, HEAD, TIMING>), dim3((unsigned)nb), dim3(32 * NT), lds, st, ws.Mbuf,
-                       ws.dT, ws.eT, ws.Tfac, ws.Tail, pstop, tdbg);
+                       ws.dT, ws.eT, ws.Tfac, ws.Tail, pstop, use_wy_back(PN_D) ? 0 : 1, tdbg);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }

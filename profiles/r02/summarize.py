@@ -9,11 +9,30 @@ import csv
 import os
 import re
 import sqlite3
+import subprocess
 import sys
 from collections import defaultdict
 
 
+_DEMANGLED = {}
+
+
+def demangle(name):
+    """rocpd stores the mangled kernel symbol (`_ZN7admmnet...kd`): c++filt it (binutils, in the ROCm image)."""
+    if name not in _DEMANGLED:
+        raw = name[:-3] if name.endswith(".kd") else name
+        out = raw
+        if raw.startswith("_Z"):
+            try:
+                out = subprocess.run(["c++filt", raw], capture_output=True, text=True, check=True).stdout.strip() or raw
+            except (OSError, subprocess.CalledProcessError):
+                out = raw
+        _DEMANGLED[name] = out
+    return _DEMANGLED[name]
+
+
 def short(name):
+    name = demangle(name)
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("admmnet::", "").replace("void ", "")
     return name.strip()

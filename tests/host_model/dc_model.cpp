@@ -170,6 +170,20 @@ int dc_solve(int n, const float *d_in, const float *e_in, float *lam_out, float 
     cx.WB.assign((size_t)n * n, 0.f);
     cx.e0.assign(e_in, e_in + n);
     std::vector<float> d(d_in, d_in + n);
+    // sstedc's slascl, as dc_kernel does it: the power of two that brings max(|d|, |e|) into [0.5, 1)
+    float orgnrm = 0.f, unscale = 1.f;
+    for (int i = 0; i < n; ++i) orgnrm = std::fmax(orgnrm, std::fmax(std::fabs(d[i]), i < n - 1 ? std::fabs(cx.e0[i]) : 0.f));
+    if (orgnrm > 0.f) {
+        int ex;
+        (void)std::frexp(orgnrm, &ex);
+        ex = std::max(-120, std::min(120, ex));
+        const float sc = std::ldexp(1.f, -ex);
+        unscale = std::ldexp(1.f, ex);
+        for (int i = 0; i < n; ++i) {
+            d[i] *= sc;
+            cx.e0[i] *= sc;
+        }
+    }
     const int nblk = dc_leaf_count(n);
     std::vector<int> bnd(nblk + 1);
     for (int b = 0; b < nblk; ++b) bnd[b] = dc_leaf_start(n, nblk, b);
@@ -217,7 +231,7 @@ int dc_solve(int n, const float *d_in, const float *e_in, float *lam_out, float 
         cur.swap(nxt);
         std::swap(src, dst);
     }
-    std::memcpy(lam_out, cx.lam.data(), sizeof(float) * n);
+    for (int i = 0; i < n; ++i) lam_out[i] = cx.lam[i] * unscale;
     std::memcpy(WT_out, src->data(), sizeof(float) * (size_t)n * n);
     if (stats) {
         stats[0] = cx.stat_defl;

@@ -78,6 +78,27 @@ def test_eigh_block(dev, n):
     assert np.abs(np.sort(w, 1) - np.linalg.eigvalsh(A64)).max() < 1e-5 * np.abs(A64).max() * max(1, n / 32)
 
 
+@pytest.mark.parametrize("n", [129, 257])
+@pytest.mark.parametrize("scale", [1e-17, 1e-10, 1e-5, 1e8, 1e16])
+def test_eigh_is_scale_invariant(dev, n, scale):
+    """torch.linalg.eigh (LAPACK) works at any scale: sstedc normalises T (slascl) before the merges, whose
+    deflation tests are absolute on a unit-norm matrix -- dc_kernel does the same with a power of two; and at n = 257
+    column norms squared outside 1e-30 .. 1e30 take the pre / post scaling of the panel kernel's branch-free reflector
+    (tridiag_panel.hip, pn_householder).  Eigenvalues scale linearly, eigenvectors do not change."""
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((3, n, n)) + 1j * rng.standard_normal((3, n, n))
+    A1 = ((X + X.conj().transpose(0, 2, 1)) / 2).astype(np.complex64)
+    As = (A1.astype(np.complex128) * scale).astype(np.complex64)
+    w, V = ops.eigh(torch.from_numpy(As).to(dev))
+    w, V = w.cpu().numpy().astype(np.float64), V.cpu().numpy().astype(np.complex128)
+    A64 = As.astype(np.complex128)
+    amax = np.abs(A64).max()
+    assert np.isfinite(w).all() and np.isfinite(V).all()
+    assert np.abs(A64 @ V - V * w[:, None, :]).max() < 3e-5 * amax
+    assert np.abs(V.conj().transpose(0, 2, 1) @ V - np.eye(n)).max() < 3e-5
+    assert np.abs(np.sort(w, 1) - np.linalg.eigvalsh(A64)).max() < 1e-5 * amax * n / 32
+
+
 def test_eigh_graded_and_clustered(dev):
     """(scalar I + tiny diagonal + large low rank): the shape of the real layer matrices, where a QL
     sweep in the wrong direction stalls -- exercises the direction choice of the QL kernel."""

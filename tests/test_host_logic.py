@@ -442,6 +442,24 @@ def test_dc_model(dc_model, name):
     assert st[3] <= 25   # middle-way iteration: a handful of passes per root, bisection fallbacks are rare
 
 
+@pytest.mark.parametrize("scale", [2.0 ** -60, 1e-10, 1e-5, 1e6, 2.0 ** 50])
+def test_dc_model_is_scale_invariant(dc_model, scale):
+    """LAPACK sstedc scales T to unit norm before the merges (slascl); without it the deflation test
+    rho |z_j| <= 8 eps max(|d|, |z|) (z normalised) calls small matrices "all negligible" -- at 1e-5 the residual was
+    1e-3 |T|.  dc_kernel / dc_model scale by a power of two, so the eigenvectors of s T are those of T and the
+    eigenvalues s times as large, to rounding."""
+    d, e = _tridiagonal_cases()["random129"]
+    n = len(d)
+    ds, es = (d.astype(np.float64) * scale).astype(np.float32), (e.astype(np.float64) * scale).astype(np.float32)
+    rc, lam, W, _ = _dc_solve(dc_model, ds, es)
+    assert rc == 0
+    T = np.diag(ds.astype(np.float64)) + np.diag(es[:-1].astype(np.float64), 1) + np.diag(es[:-1].astype(np.float64), -1)
+    tn = np.abs(T).max()
+    assert np.abs(T @ W - W * lam).max() < 4e-6 * tn
+    assert np.abs(W.T @ W - np.eye(n)).max() < 6e-6
+    assert np.abs(lam - np.linalg.eigvalsh(T)).max() < 2e-6 * tn
+
+
 @pytest.mark.parametrize("n,nb", [(9, 4), (33, 8), (129, 16), (130, 32)])
 def test_panel_blocked_tridiagonalisation_model(n, nb):
     """tests/host_model/latrd_model.py (groundwork for the matrix-core tridiagonalisation):
