@@ -216,6 +216,25 @@ def test_forward_vs_oracle_seeded(dev, shape):
         assert np.abs(a.cpu().numpy() - r.numpy()).max() < 5e-5
 
 
+@pytest.mark.parametrize("geom", [(8, 16), (16, 16)], ids=["D128", "D256"])
+@pytest.mark.parametrize("yscale", [1e-6, 1e-3, 1e3])
+def test_forward_with_small_and_large_measurements(dev, geom, yscale):
+    """The reference runs on LAPACK, which is scale invariant; measurements in volts or in ADC counts must not change
+    which path is numerically safe here either (the D&C's deflation tests are absolute on the unit-norm T)."""
+    Nb, Nd = geom
+    K, B = 3, 3
+    sd = R.make_weights(Nb, Nd, K, seed=5, head=False, perturb=0.3)
+    m = A.PhiEstADMMNet(M=Nb, N=Nd, num_layers=K).eval()
+    m.load_state_dict(sd, strict=True)
+    y, b, s, _ = synth.make_batch(B, Nb, Nd, seed=17)
+    ty, tb, ts = torch.from_numpy((y * yscale).astype(np.complex64)), torch.from_numpy(b), torch.from_numpy(s)
+    phi = m(ty.to(dev), tb.to(dev), ts.to(dev)).cpu().numpy()
+    o64 = R.forward(sd, ty, tb, ts, Nb, Nd, K, dtype="f64").numpy()
+    o32 = R.forward(sd, ty, tb, ts, Nb, Nd, K, dtype="f32").numpy()
+    assert np.isfinite(phi).all()
+    assert rel(phi, o64) <= 3 * rel(o32, o64) + 1e-5
+
+
 def test_chunking_is_invisible(dev):
     """Eigensolver work chunks (workspace reuse) must not change anything."""
     Nb, Nd, K, B = 4, 5, 3, 37
