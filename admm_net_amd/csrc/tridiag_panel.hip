@@ -380,11 +380,16 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                     for (int q0 = 0, ps = 0; q0 < 32; q0 += 4 * NW, ++ps) {   // (one pass with eight waves)
                         const int q = (q0 + 4 * wave + g) & 31, jj = q & 15;
                         v2f acc = v2f{0.f, 0.f}, acc2 = v2f{0.f, 0.f};
-                        const float2(*X)[PN_PITCH] = (q < 16) ? sh.Wp : sh.Vp;
+                        // 8-wave stage: only the dots of the panel's existing columns touch LDS (both panels + x are 64 KB
+                        // per reflector if every lane group reads: -2 %); the smaller stages lose more from the branch
+                        // between the reflector chain and these loads than they gain (+7 %)
+                        if (!ALLW || (p >= 0 && jj < j)) {
+                            const float2(*X)[PN_PITCH] = (q < 16) ? sh.Wp : sh.Vp;
 #pragma unroll
-                        for (int i = 0; i < NT; i += 2) {
-                            acc = pk_cfma_conj(acc, pk2(X[16 * i + c16][jj]), pk2(sh.xbuf[16 * i + c16]));
-                            acc2 = pk_cfma_conj(acc2, pk2(X[16 * i + 16 + c16][jj]), pk2(sh.xbuf[16 * i + 16 + c16]));
+                            for (int i = 0; i < NT; i += 2) {
+                                acc = pk_cfma_conj(acc, pk2(X[16 * i + c16][jj]), pk2(sh.xbuf[16 * i + c16]));
+                                acc2 = pk_cfma_conj(acc2, pk2(X[16 * i + 16 + c16][jj]), pk2(sh.xbuf[16 * i + 16 + c16]));
+                            }
                         }
                         dacc[ps] = make_float2(acc.x + acc2.x, acc.y + acc2.y);
                     }
