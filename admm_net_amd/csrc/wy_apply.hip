@@ -90,10 +90,13 @@ __global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *_
         __syncthreads();
         if (pp > 0) gload(pp - 1);
         // ---- Z = Y^H X  (16 reflectors x 16 columns):  Zr = Yr Xr + Yi Xi,  Zi = Yr Xi - Yi Xr
+        //      THREE real products per complex one (the "3M" form of cgemm3m) -- the kernel is bound by the matrix cores:
+        //          T1 = Yr Xr,  T2 = Yi Xi,  T3 = (Yr + Yi)(Xi - Xr)  ->  Zr = T1 + T2,  Zi = T3 + T1 - T2
+        //      (normwise the same error bound as the four-product form: |error| <= c eps |Y| |X|.)
         //      (Splitting this 256-term accumulation into block-local sums added pairwise was tried for accuracy: the
         //      distance of V to the float64 back-transform of the same reflectors moved from 9.3e-7 to 8.7e-7 only, for
         //      +28 % time -- the chain length is not what separates this kernel from the explicit-Q pair's 3.8e-7.)
-        f32x4 zr = f32x4{0.f, 0.f, 0.f, 0.f}, zi = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 t1 = f32x4{0.f, 0.f, 0.f, 0.f}, t2 = t1, t3 = t1;
 #pragma unroll
         for (int I = 0; I < 16; ++I) {
             if (I >= I0) {   // (uniform)
@@ -102,13 +105,13 @@ __global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *_
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float2 y = sh.Y[16 * I + 4 * g + q][c16];
-                    zr = __builtin_amdgcn_mfma_f32_16x16x4f32(y.x, xrq[q], zr, 0, 0, 0);
-                    zi = __builtin_amdgcn_mfma_f32_16x16x4f32(y.x, xiq[q], zi, 0, 0, 0);
-                    zr = __builtin_amdgcn_mfma_f32_16x16x4f32(y.y, xiq[q], zr, 0, 0, 0);
-                    zi = __builtin_amdgcn_mfma_f32_16x16x4f32(-y.y, xrq[q], zi, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y.x, xrq[q], t1, 0, 0, 0);
+                    t2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y.y, xiq[q], t2, 0, 0, 0);
+                    t3 = __builtin_amdgcn_mfma_f32_16x16x4f32(y.x + y.y, xiq[q] - xrq[q], t3, 0, 0, 0);
                 }
             }
         }
+        const f32x4 zr = t1 + t2, zi = t3 + t1 - t2;
         // ---- Zt = T Z:  step q: B = Z register q (k = g <-> reflector 4 g + q), A[m][k = g] = T[m][4 g + q]
         f32x4 tr = f32x4{0.f, 0.f, 0.f, 0.f}, ti = f32x4{0.f, 0.f, 0.f, 0.f};
         {
@@ -123,22 +126,23 @@ __global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *_
             }
         }
         // ---- X -= Y Zt:  step q: B = Zt register q (k = g <-> reflector 4 g + q), A[m = row][k = g] = Y[16 I + m][4 g + q]
+        //      3M again:  P1 = Yr Zr,  P2 = Yi Zi,  P3 = (Yr + Yi)(Zr + Zi)  ->  Xr -= P1 - P2,  Xi -= P3 - P1 - P2
         {
             const float trq[4] = {tr.x, tr.y, tr.z, tr.w}, tiq[4] = {ti.x, ti.y, ti.z, ti.w};
+            const float tsq[4] = {tr.x + ti.x, tr.y + ti.y, tr.z + ti.z, tr.w + ti.w};
 #pragma unroll
             for (int I = 0; I < 16; ++I) {
                 if (I >= I0) {   // (uniform)
-                    f32x4 re = xr[I], im = xi[I];
+                    f32x4 p1 = f32x4{0.f, 0.f, 0.f, 0.f}, p2 = p1, im = xi[I];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float2 y = sh.Y[16 * I + c16][4 * g + q];
-                        re = __builtin_amdgcn_mfma_f32_16x16x4f32(-y.x, trq[q], re, 0, 0, 0);
-                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(-y.x, tiq[q], im, 0, 0, 0);
-                        re = __builtin_amdgcn_mfma_f32_16x16x4f32(y.y, tiq[q], re, 0, 0, 0);
-                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(-y.y, trq[q], im, 0, 0, 0);
+                        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y.x, trq[q], p1, 0, 0, 0);
+                        p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y.y, tiq[q], p2, 0, 0, 0);
+                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(-(y.x + y.y), tsq[q], im, 0, 0, 0);
                     }
-                    xr[I] = re;
-                    xi[I] = im;
+                    xr[I] = xr[I] - p1 + p2;
+                    xi[I] = im + p1 + p2;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
