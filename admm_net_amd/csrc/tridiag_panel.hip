@@ -649,9 +649,8 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
         if (p == NT - 1) break;
         // ---- trailing update on the matrix cores: tiles (I, J), I >= J >= p + 1:  T -= V_I W_J^H + W_I V_J^H
         //      re -= Vr Wr' + Vi Wi' + Wr Vr' + Wi Vi' ;  im -= Vi Wr' - Vr Wi' + Wi Vr' - Wr Vi'   (' = block column J)
-        //      The A operands (rows of block row I; lane (m = c16, g) supplies k' = 4 g + s at step s) carry the signs,
-        //      so the B operands go from LDS to the matrix cores untouched.  One block row at a time: 24 operand
-        //      registers live across the column loop.
+        //      A operands: rows of block row I (lane (m = c16, g) supplies k' = 4 g + s at step s), B operands from LDS.
+        //      One block row at a time: 24 operand registers live across the column loop.
         c16 = c16_0;
         g = g_0;
         asm volatile("" : "+v"(c16), "+v"(g));
@@ -663,12 +662,16 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
             //  first one's -- same LDS addresses -- and all sixteen block columns' operands stay live: 85 VGPR spills)
             asm volatile("" ::: "memory");
             if (I < P1) continue;   // (uniform)
-            float nVr[4], nVi[4], pVr[4], nWr[4], nWi[4], pWr[4];
+            // Three real products per complex one (3M, as in wy_apply.hip): with ' = block column J,
+            //     S1 = Vr Wr' + Wr Vr',  S2 = Vi Wi' + Wi Vi',  S3 = (Vr + Vi)(Wr' - Wi') + (Wr + Wi)(Vr' - Vi')
+            //     re -= S1 + S2,   im -= S3 - S1 + S2
+            // 6 instead of 8 matrix-core instructions per k-step; S3 accumulates straight into im (negated A operand).
+            float aVr[4], aVi[4], nVs[4], aWr[4], aWi[4], nWs[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const float2 v = sh.Vp[16 * I + c16][4 * g + s], w = sh.Wp[16 * I + c16][4 * g + s];
-                nVr[s] = -v.x; nVi[s] = -v.y; pVr[s] = v.x;
-                nWr[s] = -w.x; nWi[s] = -w.y; pWr[s] = w.x;
+                aVr[s] = v.x; aVi[s] = v.y; nVs[s] = -(v.x + v.y);
+                aWr[s] = w.x; aWi[s] = w.y; nWs[s] = -(w.x + w.y);
             }
 #pragma unroll
             for (int J = 0; J < NT; ++J) {
@@ -680,17 +683,18 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                         bW[s] = sh.Wp[16 * J + c16][4 * g + s];
                     }
                     f32x4 re = half ? tr[NT - J] : tr[J], im = half ? ti[NT - J] : ti[J];
+                    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        re = __builtin_amdgcn_mfma_f32_16x16x4f32(nVr[s], bW[s].x, re, 0, 0, 0);
-                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(nVi[s], bW[s].x, im, 0, 0, 0);
-                        re = __builtin_amdgcn_mfma_f32_16x16x4f32(nVi[s], bW[s].y, re, 0, 0, 0);
-                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(pVr[s], bW[s].y, im, 0, 0, 0);
-                        re = __builtin_amdgcn_mfma_f32_16x16x4f32(nWr[s], bV[s].x, re, 0, 0, 0);
-                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(nWi[s], bV[s].x, im, 0, 0, 0);
-                        re = __builtin_amdgcn_mfma_f32_16x16x4f32(nWi[s], bV[s].y, re, 0, 0, 0);
-                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(pWr[s], bV[s].y, im, 0, 0, 0);
+                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aVr[s], bW[s].x, s1, 0, 0, 0);
+                        s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aVi[s], bW[s].y, s2, 0, 0, 0);
+                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(nVs[s], bW[s].x - bW[s].y, im, 0, 0, 0);
+                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aWr[s], bV[s].x, s1, 0, 0, 0);
+                        s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aWi[s], bV[s].y, s2, 0, 0, 0);
+                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(nWs[s], bV[s].x - bV[s].y, im, 0, 0, 0);
                     }
+                    re = re - s1 - s2;
+                    im = im + s1 - s2;
                     if (half) {
                         tr[NT - J] = re;
                         ti[NT - J] = im;
