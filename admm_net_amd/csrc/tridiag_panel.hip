@@ -146,8 +146,8 @@ __device__ __forceinline__ v2f pk2(float2 a) { return v2f{a.x, a.y}; }
 __device__ __forceinline__ v2f pn_lo(f32x4 a) { return v2f{a.x, a.y}; }
 __device__ __forceinline__ v2f pn_hi(f32x4 a) { return v2f{a.z, a.w}; }
 // one 16 x 16 tile (tre, tim: rows 4 g + q of column c16) in the matrix-vector product, packed FMAs over row pairs:
-//   ROW form   P[q] += T[q][c] vJ[c]            (Pr, Pi: rows 01 | 23; the caller passes vJ = 0 for a diagonal tile,
-//                                                 whose product is taken by the column form alone)
+//   ROW form   P[q] += T[q][c] vJ[c]            (Pr, Pi: rows 01 | 23; a diagonal tile is stored at half its value, so
+//                                                 that its two forms add up to T v: see the load)
 //   COL form   C    += sum_q conj(T[q][c]) vI[q]  (vIr, vIi: the four row entries of v, planar pairs; Cr, Ci pairs)
 __device__ __forceinline__ void pn_tile_mv(f32x4 tre, f32x4 tim, float2 vJ, v2f vIr01, v2f vIr23, v2f vIi01,
                                            v2f vIi23, v2f &Pr01, v2f &Pr23, v2f &Pi01, v2f &Pi23, v2f &Cr, v2f &Ci) {
@@ -240,19 +240,25 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
         if constexpr (HEAD) {
             const float2 *src = Mg + (int64_t)(16 * I + 4 * g) * D + 16 * J + c16;
             const float2 e0 = src[0], e1 = src[D], e2 = src[2 * D], e3 = src[3 * D];
-            tr[s] = f32x4{e0.x, e1.x, e2.x, e3.x};
-            ti[s] = f32x4{e0.y, e1.y, e2.y, e3.y};
+            // DIAGONAL tiles are kept at HALF their value: the matrix-vector phase then runs both of its forms on every
+            // tile without masks (T v / 2 from the row form + T^H v / 2 from the column form), 3 VALU instructions per
+            // tile and reflector less; the trailing update adds half of its term there, and the two readers of true
+            // values (the panel-column copy, the next stage's first panel) double it back.  Powers of two: exact.
+            const float dsc = (I == J) ? 0.5f : 1.0f;
+            tr[s] = f32x4{e0.x, e1.x, e2.x, e3.x} * dsc;
+            ti[s] = f32x4{e0.y, e1.y, e2.y, e3.y} * dsc;
         } else {
             const float2 e0 = tail[pn_tail_at(I, J, 0, lane)], e1 = tail[pn_tail_at(I, J, 1, lane)],
                          e2 = tail[pn_tail_at(I, J, 2, lane)], e3 = tail[pn_tail_at(I, J, 3, lane)];
             tr[s] = f32x4{e0.x, e1.x, e2.x, e3.x};
             ti[s] = f32x4{e0.y, e1.y, e2.y, e3.y};
-            if (J == 0) {   // (uniform) the first panel's columns
+            if (J == 0) {   // (uniform) the first panel's columns (the hand-over set holds the diagonal tiles halved)
+                const float cs = (I == 0) ? 2.0f : 1.0f;
                 float2 *dst = &sh.Ap[16 * I + 4 * g][c16];
-                dst[0] = e0;
-                dst[PN_PITCH] = e1;
-                dst[2 * PN_PITCH] = e2;
-                dst[3 * PN_PITCH] = e3;
+                dst[0] = make_float2(e0.x * cs, e0.y * cs);
+                dst[PN_PITCH] = make_float2(e1.x * cs, e1.y * cs);
+                dst[2 * PN_PITCH] = make_float2(e2.x * cs, e2.y * cs);
+                dst[3 * PN_PITCH] = make_float2(e3.x * cs, e3.y * cs);
             }
         }
     }
@@ -471,12 +477,10 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                             v2f Cr = z2, Ci = z2;
                             if (J >= J0 && J <= IB) {   // (uniform)
                                 const float2 vJ = vJq[k];
-                                const float mB = (J == IB) ? 0.f : 1.f, mA = (J == IA) ? 0.f : 1.f;
-                                pn_tile_mv(tr[J], ti[J], make_float2(vJ.x * mB, vJ.y * mB), Br01, Br23, Bi01, Bi23, PBr01,
-                                           PBr23, PBi01, PBi23, Cr, Ci);
+                                pn_tile_mv(tr[J], ti[J], vJ, Br01, Br23, Bi01, Bi23, PBr01, PBr23, PBi01, PBi23, Cr, Ci);
                                 if (J <= IA)
-                                    pn_tile_mv(tr[NT - J], ti[NT - J], make_float2(vJ.x * mA, vJ.y * mA), Ar01, Ar23, Ai01,
-                                               Ai23, PAr01, PAr23, PAi01, PAi23, Cr, Ci);
+                                    pn_tile_mv(tr[NT - J], ti[NT - J], vJ, Ar01, Ar23, Ai01, Ai23, PAr01, PAr23, PAi01,
+                                               PAi23, Cr, Ci);
                             }
                             cx[k] = Cr.x + Cr.y;
                             cy[k] = Ci.x + Ci.y;
@@ -665,13 +669,13 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
             // Three real products per complex one (3M, as in wy_apply.hip): with ' = block column J,
             //     S1 = Vr Wr' + Wr Vr',  S2 = Vi Wi' + Wi Vi',  S3 = (Vr + Vi)(Wr' - Wi') + (Wr + Wi)(Vr' - Vi')
             //     re -= S1 + S2,   im -= S3 - S1 + S2
-            // 6 instead of 8 matrix-core instructions per k-step; S3 accumulates straight into im (negated A operand).
+            // 6 instead of 8 matrix-core instructions per k-step.
             float aVr[4], aVi[4], nVs[4], aWr[4], aWi[4], nWs[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const float2 v = sh.Vp[16 * I + c16][4 * g + s], w = sh.Wp[16 * I + c16][4 * g + s];
-                aVr[s] = v.x; aVi[s] = v.y; nVs[s] = -(v.x + v.y);
-                aWr[s] = w.x; aWi[s] = w.y; nWs[s] = -(w.x + w.y);
+                aVr[s] = v.x; aVi[s] = v.y; nVs[s] = v.x + v.y;
+                aWr[s] = w.x; aWi[s] = w.y; nWs[s] = w.x + w.y;
             }
 #pragma unroll
             for (int J = 0; J < NT; ++J) {
@@ -683,18 +687,19 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                         bW[s] = sh.Wp[16 * J + c16][4 * g + s];
                     }
                     f32x4 re = half ? tr[NT - J] : tr[J], im = half ? ti[NT - J] : ti[J];
-                    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+                    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aVr[s], bW[s].x, s1, 0, 0, 0);
                         s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aVi[s], bW[s].y, s2, 0, 0, 0);
-                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(nVs[s], bW[s].x - bW[s].y, im, 0, 0, 0);
+                        s3 = __builtin_amdgcn_mfma_f32_16x16x4f32(nVs[s], bW[s].x - bW[s].y, s3, 0, 0, 0);
                         s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aWr[s], bV[s].x, s1, 0, 0, 0);
                         s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aWi[s], bV[s].y, s2, 0, 0, 0);
-                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(nWs[s], bV[s].x - bV[s].y, im, 0, 0, 0);
+                        s3 = __builtin_amdgcn_mfma_f32_16x16x4f32(nWs[s], bV[s].x - bV[s].y, s3, 0, 0, 0);
                     }
-                    re = re - s1 - s2;
-                    im = im + s1 - s2;
+                    const float usc = (J == I) ? 0.5f : 1.0f;   // (a diagonal tile is held at half its value)
+                    re = re - (s1 + s2) * usc;
+                    im = im + ((s1 - s2) - s3) * usc;
                     if (half) {
                         tr[NT - J] = re;
                         ti[NT - J] = im;
@@ -703,11 +708,12 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                         ti[J] = im;
                     }
                     if (J == P1) {   // (uniform) the next panel's columns, up to date: rows 16 I + 4 g + q, column c16
+                        const float cs = (J == I) ? 2.0f : 1.0f;
                         float2 *dst = &sh.Ap[16 * I + 4 * g][c16];
-                        dst[0] = make_float2(re.x, im.x);
-                        dst[PN_PITCH] = make_float2(re.y, im.y);
-                        dst[2 * PN_PITCH] = make_float2(re.z, im.z);
-                        dst[3 * PN_PITCH] = make_float2(re.w, im.w);
+                        dst[0] = make_float2(re.x * cs, im.x * cs);
+                        dst[PN_PITCH] = make_float2(re.y * cs, im.y * cs);
+                        dst[2 * PN_PITCH] = make_float2(re.z * cs, im.z * cs);
+                        dst[3 * PN_PITCH] = make_float2(re.w * cs, im.w * cs);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);   // operands of block column J + 1 are not hoisted above these MFMAs
