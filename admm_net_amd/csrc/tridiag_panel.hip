@@ -197,6 +197,14 @@ __device__ __forceinline__ void pn_quad_group_sum2(const float (&x)[4], const fl
     ty = c + d;
 }
 
+// One step of the transposing butterfly sum: this lane keeps `lo` (hi lanes: `hi`), its DPP partner sends the value it
+// does not keep; returns kept + received.
+template <int CTRL>
+__device__ __forceinline__ float pn_keep_add(bool hi_lane, float lo, float hi) {
+    const float keep = hi_lane ? hi : lo, send = hi_lane ? lo : hi;
+    return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), CTRL, 0xF, 0xF, false));
+}
+
 // slot s of wave w: tile (IB, s) for s <= IB, tile (IA, NT - s) otherwise   (IA = w, IB = NT - 1 - w)
 #define PN_SLOT_IJ(s, I, J)            \
     int I, J;                          \
@@ -493,30 +501,66 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                     __builtin_amdgcn_sched_barrier(0);   // keep each pass's loads inside it (VGPR budget)
                 }
                 mark(2);
-                if (IB >= J0) {
-                    float2 P[4] = {make_float2(PBr01.x, PBi01.x), make_float2(PBr01.y, PBi01.y),
-                                   make_float2(PBr23.x, PBi23.x), make_float2(PBr23.y, PBi23.y)};
+                // Row sums of the 8 (or 16) partial values per lane over the 16 lanes of a row, as a transposing butterfly:
+                // at each step a lane keeps one half of its values, hands the other half to its mirror partner and adds
+                // what it receives (2 selects + 1 DPP add per pair; mirror over 16 / 8 / 4 / 2 lanes) -- 15 pairs = 45
+                // instructions for 16 values instead of 64 dependent DPP adds, and lane c16 ends up with the total of
+                // value c16 = 8 (block row IA?) + 2 q + (imaginary?), which it stores itself.
+                // (8-wave stage only: -2 % there, +6 % in the 4-wave stage, which keeps the plain DPP sums)
+                if constexpr (ALLW) {
+                    const bool b3 = c16 & 8, b2 = c16 & 4, b1 = c16 & 2, b0 = c16 & 1;
+                    float total;
+                    const float vB[8] = {PBr01.x, PBi01.x, PBr01.y, PBi01.y, PBr23.x, PBi23.x, PBr23.y, PBi23.y};
+                    if (IA >= J0) {   // (uniform) both block rows live
+                        const float vA[8] = {PAr01.x, PAi01.x, PAr01.y, PAi01.y, PAr23.x, PAi23.x, PAr23.y, PAi23.y};
+                        float w8[8], w4[4], w2[2];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        P[q].x = pn_row16_sum(P[q].x);
-                        P[q].y = pn_row16_sum(P[q].y);
+                        for (int m = 0; m < 8; ++m) w8[m] = pn_keep_add<0x140>(b3, vB[m], vA[m]);   // row_mirror
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) w4[m] = pn_keep_add<0x141>(b2, w8[m], w8[m + 4]);   // row_half_mirror
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) w2[m] = pn_keep_add<0x1B>(b1, w4[m], w4[m + 2]);   // quad_perm [3,2,1,0]
+                        total = pn_keep_add<0xB1>(b0, w2[0], w2[1]);                                 // quad_perm [1,0,3,2]
+                        const int q = (c16 >> 1) & 3, I = b3 ? IA : IB;
+                        reinterpret_cast<float *>(&sh.yrow[16 * I + 4 * g + q])[c16 & 1] = total;
+                    } else if (IB >= J0) {   // (uniform) one block row: value (c16 & 7) on lane pairs {c16, c16 ^ 8}
+                        float w4[4], w2[2];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) w4[m] = pn_keep_add<0x141>(b2, vB[m], vB[m + 4]);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) w2[m] = pn_keep_add<0x1B>(b1, w4[m], w4[m + 2]);
+                        total = pn_keep_add<0xB1>(b0, w2[0], w2[1]);
+                        total += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, total), 0x128,
+                                                                                        0xF, 0xF, false));   // + lane c16 ^ 8 (row_ror:8)
+                        const int q = (c16 >> 1) & 3;
+                        if (!b3) reinterpret_cast<float *>(&sh.yrow[16 * IB + 4 * g + q])[c16 & 1] = total;
                     }
-                    if (c16 == 0) {
+                } else {
+                    if (IB >= J0) {
+                        float2 P[4] = {make_float2(PBr01.x, PBi01.x), make_float2(PBr01.y, PBi01.y),
+                                       make_float2(PBr23.x, PBi23.x), make_float2(PBr23.y, PBi23.y)};
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) sh.yrow[16 * IB + 4 * g + q] = P[q];
+                        for (int q = 0; q < 4; ++q) {
+                            P[q].x = pn_row16_sum(P[q].x);
+                            P[q].y = pn_row16_sum(P[q].y);
+                        }
+                        if (c16 == 0) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) sh.yrow[16 * IB + 4 * g + q] = P[q];
+                        }
                     }
-                }
-                if (IA >= J0) {
-                    float2 P[4] = {make_float2(PAr01.x, PAi01.x), make_float2(PAr01.y, PAi01.y),
-                                   make_float2(PAr23.x, PAi23.x), make_float2(PAr23.y, PAi23.y)};
+                    if (IA >= J0) {
+                        float2 P[4] = {make_float2(PAr01.x, PAi01.x), make_float2(PAr01.y, PAi01.y),
+                                       make_float2(PAr23.x, PAi23.x), make_float2(PAr23.y, PAi23.y)};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        P[q].x = pn_row16_sum(P[q].x);
-                        P[q].y = pn_row16_sum(P[q].y);
-                    }
-                    if (c16 == 0) {
+                        for (int q = 0; q < 4; ++q) {
+                            P[q].x = pn_row16_sum(P[q].x);
+                            P[q].y = pn_row16_sum(P[q].y);
+                        }
+                        if (c16 == 0) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) sh.yrow[16 * IA + 4 * g + q] = P[q];
+                            for (int q = 0; q < 4; ++q) sh.yrow[16 * IA + 4 * g + q] = P[q];
+                        }
                     }
                 }
                 mark(3);
