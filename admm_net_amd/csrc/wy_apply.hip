@@ -35,7 +35,7 @@ struct WyShared {
     float2 T[16][WY_PITCH];
 };
 
-__global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *__restrict__ Mbuf,
+__global__ __launch_bounds__(WY_THREADS, 3) void wy_apply_kernel(const float2 *__restrict__ Mbuf,
                                                                  const float2 *__restrict__ Tfac,
                                                                  const float *__restrict__ Wbuf, int64_t wt_off,
                                                                  float *__restrict__ VT, int nb) {
@@ -66,8 +66,10 @@ __global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *_
         xi[I] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // the panel image travels global -> registers -> LDS; the NEXT panel's loads are issued before this panel's products,
-    // so their latency hides behind the matrix-core work instead of sitting between two barriers
+    // the panel image travels global -> registers -> LDS at the head of each panel.  (Issuing the NEXT panel's loads
+    // before this panel's products hid their latency at two waves per SIMD, 7.5 -> 6.7 ms; the 34 registers of that
+    // prefetch are what stood between the kernel and THREE waves per SIMD, which hides it as well and keeps the matrix
+    // cores busier: 5.13 -> 5.04 ms.)
     float2 ypre[16], tpre;
     auto gload = [&](int pp) {
         const int u0 = 16 * (pp - 1) + 1, I0 = (u0 < 0 ? 0 : u0) >> 4;
@@ -78,17 +80,16 @@ __global__ __launch_bounds__(WY_THREADS, 2) void wy_apply_kernel(const float2 *_
         }
         tpre = Tg[pp * 256 + tid];
     };
-    gload(16);
     for (int pp = 16; pp >= 0; --pp) {
         const int u0 = 16 * (pp - 1) + 1;          // reflector of slot jj: u0 + jj (absent outside 0 .. D - 1)
         const int I0 = (u0 < 0 ? 0 : u0) >> 4;     // first block row the panel touches
+        gload(pp);
         __syncthreads();                           // the previous panel's LDS image is no longer read
         // ---- the panel: Y[r][jj] = v_{u0 + jj}[r] (reflector row u of the image), T
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) sh.Y[tid][jj] = ypre[jj];
         sh.T[tid >> 4][tid & 15] = tpre;
         __syncthreads();
-        if (pp > 0) gload(pp - 1);
         // ---- Z = Y^H X  (16 reflectors x 16 columns):  Zr = Yr Xr + Yi Xi,  Zi = Yr Xi - Yi Xr
         //      THREE real products per complex one (the "3M" form of cgemm3m) -- the kernel is bound by the matrix cores:
         //          T1 = Yr Xr,  T2 = Yi Xi,  T3 = (Yr + Yi)(Xi - Xr)  ->  Zr = T1 + T2,  Zi = T3 + T1 - T2
