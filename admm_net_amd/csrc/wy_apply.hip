@@ -70,25 +70,30 @@ __global__ __launch_bounds__(WY_THREADS, 3) void wy_apply_kernel(const float2 *_
     // before this panel's products hid their latency at two waves per SIMD, 7.5 -> 6.7 ms; the 34 registers of that
     // prefetch are what stood between the kernel and THREE waves per SIMD, which hides it as well and keeps the matrix
     // cores busier: 5.13 -> 5.04 ms.)
-    float2 ypre[16], tpre;
-    auto gload = [&](int pp) {
+    // (in two halves of eight reflectors: 17 staging registers instead of 34 -- at three waves per SIMD the budget is
+    //  168 and the whole panel in flight spilled 14 registers to scratch, +0.37 MB of HBM traffic per matrix)
+    float2 ypre[8], tpre;
+    auto gload = [&](int pp, int h) {
         const int u0 = 16 * (pp - 1) + 1, I0 = (u0 < 0 ? 0 : u0) >> 4;
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const int uu = u0 + jj;
+        for (int jj = 0; jj < 8; ++jj) {
+            const int uu = u0 + 8 * h + jj;
             ypre[jj] = (uu >= 0 && uu < D && tid >= 16 * I0) ? Mg[(int64_t)uu * D + tid] : make_float2(0.f, 0.f);
         }
-        tpre = Tg[pp * 256 + tid];
+        if (h == 0) tpre = Tg[pp * 256 + tid];
     };
     for (int pp = 16; pp >= 0; --pp) {
         const int u0 = 16 * (pp - 1) + 1;          // reflector of slot jj: u0 + jj (absent outside 0 .. D - 1)
         const int I0 = (u0 < 0 ? 0 : u0) >> 4;     // first block row the panel touches
-        gload(pp);
+        gload(pp, 0);
         __syncthreads();                           // the previous panel's LDS image is no longer read
         // ---- the panel: Y[r][jj] = v_{u0 + jj}[r] (reflector row u of the image), T
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) sh.Y[tid][jj] = ypre[jj];
+        for (int jj = 0; jj < 8; ++jj) sh.Y[tid][jj] = ypre[jj];
         sh.T[tid >> 4][tid & 15] = tpre;
+        gload(pp, 1);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) sh.Y[tid][8 + jj] = ypre[jj];
         __syncthreads();
         // ---- Z = Y^H X  (16 reflectors x 16 columns):  Zr = Yr Xr + Yi Xi,  Zi = Yr Xi - Yi Xr
         //      THREE real products per complex one (the "3M" form of cgemm3m) -- the kernel is bound by the matrix cores:
@@ -130,7 +135,6 @@ __global__ __launch_bounds__(WY_THREADS, 3) void wy_apply_kernel(const float2 *_
         //      3M again:  P1 = Yr Zr,  P2 = Yi Zi,  P3 = (Yr + Yi)(Zr + Zi)  ->  Xr -= P1 - P2,  Xi -= P3 - P1 - P2
         {
             const float trq[4] = {tr.x, tr.y, tr.z, tr.w}, tiq[4] = {ti.x, ti.y, ti.z, ti.w};
-            const float tsq[4] = {tr.x + ti.x, tr.y + ti.y, tr.z + ti.z, tr.w + ti.w};
 #pragma unroll
             for (int I = 0; I < 16; ++I) {
                 if (I >= I0) {   // (uniform)
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(WY_THREADS, 3) void wy_apply_kernel(const float2 *_
                         const float2 y = sh.Y[16 * I + c16][4 * g + q];
                         p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y.x, trq[q], p1, 0, 0, 0);
                         p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y.y, tiq[q], p2, 0, 0, 0);
-                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(-(y.x + y.y), tsq[q], im, 0, 0, 0);
+                        im = __builtin_amdgcn_mfma_f32_16x16x4f32(-(y.x + y.y), trq[q] + tiq[q], im, 0, 0, 0);
                     }
                     xr[I] = xr[I] - p1 + p2;
                     xi[I] = im + p1 + p2;
