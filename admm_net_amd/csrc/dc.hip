@@ -11,7 +11,8 @@
 // The scalar pieces live in dc_core.h and are shared with tests/host_model/dc_model.cpp.
 //
 // Layouts: eigenvector blocks are kept transposed, WT[j][i] = W[i][j] (j = eigenvalue index), in
-// two ping-pong n x n global buffers per matrix (L2 resident); U of every merge goes to a third.
+// two ping-pong n x n global buffers per matrix; the rank-one eigenvectors U of a merge exist only in
+// registers (regenerated under the MFMA); a third n x n region takes W row-major for the consumers that want it.
 #include <cstdio>
 #include <cstdlib>
 
@@ -26,6 +27,7 @@ constexpr int DC_THREADS = 256;
 constexpr int DC_LS = 8;          // nominal leaf size (dc_leaf_start in dc_core.h spreads the remainder)
 constexpr int DC_MAXLEAF = 33;    // n <= 8 * 33 + 7
 constexpr int DC_MAXLS = 2 * DC_LS;   // a single leaf (n < 16) has up to 15 rows
+constexpr int DC_FULL = 1 << 30;      // flag on a source-column index: a deflation rotation has filled all its rows
 
 // leaf scratch: Z of every leaf as [maxrows][maxrows | 1] (odd pitch: the team's row-per-lane accesses spread
 // over the banks)
@@ -42,6 +44,7 @@ struct DcShared {
     int mx[DC_MAXLEAF][2];   // max |d|, max |z| of a merge as float bit patterns (non-negative: integer order)
     int fail;
     int nrm;                 // max |d|, |e| of the whole matrix (float bits)
+    int kc[DC_MAXLEAF][2];   // per merge: non-deflated source columns with rows in the first / second block
 };
 
 template <int OCC>
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                                                         const float *__restrict__ eT, float *__restrict__ Wbuf,
                                                         float *__restrict__ wout, float *__restrict__ w0out,
                                                         int *__restrict__ logn, int32_t *__restrict__ status,
-                                                        unsigned long long *__restrict__ ptime, int rowmajor) {
+                                                        unsigned long long *__restrict__ ptime, int rowmajor, int poison) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ DcShared sh;
     const int tid = threadIdx.x;
@@ -130,9 +133,12 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         }
         return;
     }
-    // both ping-pong buffers start at zero: every level writes only inside its diagonal blocks and
-    // the next level reads the (zero) off-diagonal blocks of the pair it merges
-    for (int64_t i = tid; i < (int64_t)2 * n * n; i += DC_THREADS) WA[i] = 0.f;
+    // The ping-pong buffers are NOT cleared (0.53 MB of zero writes per matrix at n = 257): every level writes its
+    // diagonal blocks in full, and a reader of a source column takes the rows outside that column's own block as zero
+    // unless a deflation rotation has filled them (DC_FULL on the column index).  ADMMNET_DC_POISON=1 (tests) fills the
+    // buffers with NaN instead, so that any read of a never-written element shows.
+    if (poison)
+        for (int64_t i = tid; i < (int64_t)2 * n * n; i += DC_THREADS) WA[i] = __int_as_float(0x7fc00000);
     // LAPACK sstedc scales T to unit max-norm first (slascl): the deflation tests compare rho |z_j| (z normalised) with
     // 8 eps max(|d|, |z|), which means "negligible against T" only on a matrix of norm ~ 1.  Scaled here by the power
     // of two that brings max(|d|, |e|) into [0.5, 1) -- exact, so a matrix that already is of that size takes the very
@@ -305,10 +311,13 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         rr[q] = rot[a + min(r0 + q, nr - 1)];
-                        xo[q] = (a + perm[a + rr[q].pa]) * n + a + i;
-                        yo[q] = (a + perm[a + rr[q].pb]) * n + a + i;
-                        xv[q] = Ws[xo[q]];
-                        yv[q] = Ws[yo[q]];
+                        // (a column is read from memory before any rotation has written it: its rows outside its own
+                        //  block are zero by definition, not by content; the flag may be set concurrently, hence masked)
+                        const int ca = perm[a + rr[q].pa] & ~DC_FULL, cb2 = perm[a + rr[q].pb] & ~DC_FULL;
+                        xo[q] = (a + ca) * n + a + i;
+                        yo[q] = (a + cb2) * n + a + i;
+                        xv[q] = ((ca < n1) == (i < n1)) ? Ws[xo[q]] : 0.f;
+                        yv[q] = ((cb2 < n1) == (i < n1)) ? Ws[yo[q]] : 0.f;
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -321,6 +330,11 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                         }
                     }
                 }
+            }
+            // both columns of a rotation now hold all nn rows (written above for every i)
+            for (int r = tl; r < nr; r += ts) {
+                atomicOr(&perm[a + rot[a + r].pa], DC_FULL);
+                atomicOr(&perm[a + rot[a + r].pb], DC_FULL);
             }
             {   // when the team has two lanes per root, adjacent lanes share one: each sums every other pole
                 // and one DPP swap adds the halves (one code path: G = 1 makes the swap a no-op)
@@ -379,6 +393,32 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         //     vectors themselves are regenerated inside the GEMM (two subtractions, a reciprocal and two
         //     products per entry, hidden under the MFMA) instead of making a round trip through memory.
         if (act) {
+            // The merged eigenvector block is [W1 0; 0 W2] U: the rows of the first block only see the source columns
+            // of the first block (and the columns a deflation rotation filled), likewise the second -- as slaed3's two
+            // GEMMs.  kl1 / kl2 list the non-deflated merged positions by that criterion, in ascending order (placed by
+            // counting: deterministic), in the memory of the rotation list (dead since P3).
+            {
+                int *kl1 = reinterpret_cast<int *>(rot) + a, *kl2 = kl1 + NP;
+                for (int p = tl; p < k; p += ts) {
+                    const int cc = cidx[a + p];
+                    const bool t1 = (cc & DC_FULL) || (cc & ~DC_FULL) < n1, t2 = (cc & DC_FULL) || (cc & ~DC_FULL) >= n1;
+                    int r1 = 0, r2 = 0;
+#pragma unroll 4
+                    for (int q = 0; q < p; ++q) {
+                        const int cq = cidx[a + q];
+                        const bool f = cq & DC_FULL, lo = (cq & ~DC_FULL) < n1;
+                        r1 += (f || lo);
+                        r2 += (f || !lo);
+                    }
+                    if (t1) kl1[r1] = p;
+                    if (t2) kl2[r2] = p;
+                    if (p == k - 1) {
+                        sh.kc[team][0] = r1 + (t1 ? 1 : 0);
+                        sh.kc[team][1] = r2 + (t2 ? 1 : 0);
+                    }
+                }
+                if (k == 0 && tl == 0) sh.kc[team][0] = sh.kc[team][1] = 0;
+            }
             const int G = (2 * k <= ts) ? 2 : 1;   // two lanes per root: each sums every other entry
             const int sub = (G == 2) ? (tl & 1) : 0;
             for (int j = (G == 2) ? (tl >> 1) : tl; j < k; j += ts / G) {
@@ -402,12 +442,17 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         if (act) {
             const int cw = ts >= 32 ? 32 : ts;   // lanes per column copy
             for (int p = k + (tl / cw); p < nn; p += max(1, ts / cw)) {
-                const float *xs = Ws + (int64_t)(a + cidx[a + p]) * n + a;
+                const int cc = cidx[a + p], col = cc & ~DC_FULL;
+                const bool full = cc & DC_FULL;
+                const float *xs = Ws + (int64_t)(a + col) * n + a;
                 float *xd = Wd + (int64_t)(a + rnk[a + p]) * n + a;
                 for (int i = tl & (cw - 1); i < nn; i += 4 * cw) {   // four loads in flight per lane
                     float v[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (i + q * cw < nn) ? xs[i + q * cw] : 0.f;
+                    for (int q = 0; q < 4; ++q) {
+                        const int iq = i + q * cw;
+                        v[q] = (iq < nn && (full || ((col < n1) == (iq < n1)))) ? xs[iq] : 0.f;
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (i + q * cw < nn) xd[i + q * cw] = v[q];
@@ -430,7 +475,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
             int gbase = 0;   // tiles of all merges of the level are dealt round-robin to the 4 waves
             for (int mm = 0; mm < nm; ++mm) {
                 const int ma = bn[2 * mm], mc = bn[2 * mm + 2];
-                const int mnn = mc - ma, mk = sh.kk[mm];
+                const int mnn = mc - ma, mk = sh.kk[mm], mn1 = bn[2 * mm + 1] - ma;
                 // work unit: two stacked 32 x 32 tiles (64 roots j) x 32 rows i; the B operand
                 // (source columns, the only memory stream) is shared by the pair, the A operand
                 // U[kk][j] = zh_kk / ((d_kk - d_org(j)) - tau_j) / ||u_j|| is generated in registers
@@ -446,20 +491,29 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                     const float dorg1 = dl[ma + org[jb]], tau1 = tau[jb], inv1 = jv1 ? un[jb] : 0.f;
                     const int io = iv ? i0 + r : 0;
                     f32x16 acc0 = {0}, acc1 = {0};
-                    for (int k0 = 0; k0 < mk; k0 += 32) {   // 16 K-steps per batch: all loads first
+                    // row tile inside one block: only that block's source columns (list), no masks; a tile that straddles
+                    // the block boundary (one per merge unless n1 is a multiple of 32) takes every column and masks
+                    const bool blk1 = min(i0 + 32, mnn) <= mn1, blk2 = i0 >= mn1;
+                    const int *kl = reinterpret_cast<const int *>(rot) + ma + (blk2 ? NP : 0);
+                    const int kcnt = blk1 ? sh.kc[mm][0] : (blk2 ? sh.kc[mm][1] : mk);
+                    const bool listed = blk1 || blk2;
+                    for (int k0 = 0; k0 < kcnt; k0 += 32) {   // 16 K-steps per batch: all loads first
                         float bv[16];
 #pragma unroll
                         for (int s16 = 0; s16 < 16; ++s16) {
-                            const int kq = k0 + 2 * s16 + kh;
-                            const bool kv = kq < mk;
-                            const float b_ = Ws[(ma + cidx[ma + (kv ? kq : 0)]) * n + ma + io];
-                            bv[s16] = (kv && iv) ? b_ : 0.f;
+                            const int ki = k0 + 2 * s16 + kh;
+                            const bool kv = ki < kcnt;
+                            const int kq = listed ? kl[kv ? ki : 0] : (kv ? ki : 0);
+                            const int cc = cidx[ma + kq], col = cc & ~DC_FULL;
+                            const float b_ = Ws[(ma + col) * n + ma + io];
+                            const bool ok = listed || (cc & DC_FULL) || ((col < mn1) == (io < mn1));
+                            bv[s16] = (kv && iv && ok) ? b_ : 0.f;
                         }
 #pragma unroll
                         for (int s16 = 0; s16 < 16; ++s16) {
-                            const int kq = k0 + 2 * s16 + kh;
-                            const bool kv = kq < mk;
-                            const int kc = ma + (kv ? kq : 0);
+                            const int ki = k0 + 2 * s16 + kh;
+                            const bool kv = ki < kcnt;
+                            const int kc = ma + (listed ? kl[kv ? ki : 0] : (kv ? ki : 0));
                             const float zk = kv ? zh[kc] : 0.f, dk = dl[kc];
                             const float a0 = kv ? fdiv_fast(zk, (dk - dorg0) - tau0) * inv0 : 0.f;
                             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[s16], acc0, 0, 0, 0);
@@ -605,18 +659,21 @@ int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, 
         return ADMMNET_E_ARG;
     }
     const size_t lds = dc_lds_bytes(n);
-    static const int occ = getenv("ADMMNET_DC_OCC") ? atoi(getenv("ADMMNET_DC_OCC")) : 5;   // tuning knob
-    auto kern = occ >= 8 ? dc_kernel<8> : occ == 6 ? dc_kernel<6> : dc_kernel<5>;
+    // (4 workgroups per CU is what the 36 KB of LDS per workgroup admit at n = 257 anyway; compiled for 5 the kernel has
+    //  96 registers and the block-structured product below spills inside its loops: 3.34 ms -> 4.7 ms per 4096 matrices)
+    static const int occ = getenv("ADMMNET_DC_OCC") ? atoi(getenv("ADMMNET_DC_OCC")) : 4;   // tuning knob
+    auto kern = occ >= 8 ? dc_kernel<8> : occ == 6 ? dc_kernel<6> : occ == 4 ? dc_kernel<4> : dc_kernel<5>;
     ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
     static const bool timing = getenv("ADMMNET_DC_TIMING") != nullptr;   // developer aid, never on by default
+    static const bool poison = getenv("ADMMNET_DC_POISON") != nullptr;   // tests: NaN in every never-written element
     unsigned long long *ptime = nullptr;
     if (timing) {
         ADMM_HIP(hipMalloc(&ptime, 96 * sizeof(unsigned long long)));
         ADMM_HIP(hipMemsetAsync(ptime, 0, 96 * sizeof(unsigned long long), st));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(DC_THREADS), lds, st, n, ws.dT, ws.eT, ws.Wdc, ws.w,
-                       ws.w0, ws.logn, status, ptime, rowmajor ? 1 : 0);
+                       ws.w0, ws.logn, status, ptime, rowmajor ? 1 : 0, poison ? 1 : 0);
     ADMM_HIP(hipGetLastError());
     if (timing) {
         unsigned long long h[96];

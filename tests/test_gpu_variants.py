@@ -43,6 +43,7 @@ VARIANTS = {
     "explicit_q": {"ADMMNET_BACK": "q"},               # D = 256: panel tridiagonalisation, explicit Q + Q W
     "panel_one_stage": {"ADMMNET_PN_SPLIT": "0"},      # D = 256: the whole panel reduction in the 8-wave kernel
     "panel_two_stages": {"ADMMNET_PN_SPLIT": "8"},     # D = 256: panels 0..7 | 8..15 (default: 0..7 | 8..11 | 12..15)
+    "dc_poison": {"ADMMNET_DC_POISON": "1"},           # D&C ping-pong buffers start as NaN instead of whatever they hold
 }
 
 
@@ -57,3 +58,47 @@ def test_variant_matches_reference_fixtures(variant):
     assert len(errs) == 3
     for name, e in errs.items():
         assert e < 1e-4, (variant, name, e)
+
+
+POISON_CHILD = r"""
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+from admm_net_amd import ops
+rng = np.random.default_rng(3)
+worst = 0.0
+for n in (17, 65, 129, 130, 200, 257):
+    mats = []
+    X = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    mats.append((X + X.conj().T) / 2)                                            # generic: no deflation
+    U = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    mats.append(0.3 * np.eye(n) + 1e-4 * np.diag(rng.standard_normal(n)) + U @ np.diag([5.0, -7.0, 2.0]) @ U.conj().T)
+    Q, _ = np.linalg.qr(X)
+    lam = np.repeat(rng.standard_normal(max(2, n // 8)), 8)[:n]                  # eightfold eigenvalues: rotations
+    lam = np.concatenate([lam, rng.standard_normal(n - len(lam))])
+    mats.append((Q * lam) @ Q.conj().T)
+    mats.append(np.diag(rng.standard_normal(n)).astype(complex))                 # everything deflates
+    A = np.stack([(M + M.conj().T) / 2 for M in mats]).astype(np.complex64)
+    w, V = ops.eigh(torch.from_numpy(A).cuda())
+    w, V = w.cpu().numpy().astype(np.float64), V.cpu().numpy().astype(np.complex128)
+    assert np.isfinite(w).all() and np.isfinite(V).all(), n
+    A64 = A.astype(np.complex128)
+    for i in range(len(mats)):
+        sc = np.abs(A64[i]).max()
+        worst = max(worst, np.abs(A64[i] @ V[i] - V[i] * w[i][None, :]).max() / sc,
+                    np.abs(V[i].conj().T @ V[i] - np.eye(n)).max())
+print("RESULT", worst)
+"""
+
+
+def test_dc_never_reads_an_unwritten_element():
+    """dc_kernel does not clear its ping-pong eigenvector buffers (0.53 MB of zero writes per matrix at n = 257): rows of
+    a source column outside its own block are zero by definition (a select), not by content, unless a deflation
+    rotation filled them.  With the buffers poisoned by NaN, generic, clustered, multiple-eigenvalue and diagonal
+    matrices must come back finite and accurate."""
+    env = dict(os.environ, ADMMNET_DC_POISON="1")
+    p = subprocess.run([sys.executable, "-c", POISON_CHILD.format(root=ROOT)], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    worst = float([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1].split()[1])
+    assert worst < 5e-5
