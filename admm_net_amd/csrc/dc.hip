@@ -446,15 +446,17 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                 const bool full = cc & DC_FULL;
                 const float *xs = Ws + (int64_t)(a + col) * n + a;
                 float *xd = Wd + (int64_t)(a + rnk[a + p]) * n + a;
-                for (int i = tl & (cw - 1); i < nn; i += 4 * cw) {   // four loads in flight per lane
-                    float v[4];
+                // nine loads in flight per lane: one trip per column at n = 257 (the loop is bound by the L2 round trip,
+                // and most columns of the layer matrices deflate -- 230 of 257 at the top level)
+                for (int i = tl & (cw - 1); i < nn; i += 9 * cw) {
+                    float v[9];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < 9; ++q) {
                         const int iq = i + q * cw;
                         v[q] = (iq < nn && (full || ((col < n1) == (iq < n1)))) ? xs[iq] : 0.f;
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < 9; ++q)
                         if (i + q * cw < nn) xd[i + q * cw] = v[q];
                 }
             }
