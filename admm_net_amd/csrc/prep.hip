@@ -173,27 +173,50 @@ __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
         // Lower triangle only (G, Z and C are Hermitian; row D = the arrow row lies in it): half the G / Z streams,
         // about half the image.  Entries inside a diagonal 16-block also write their mirror, the arrow COLUMN of the
         // image is the conjugate of the arrow row.
-        for (int idx = tid; idx < n * n; idx += PR_THREADS) {
-            const int i = idx / n, j = idx - i * n;
-            if (j > i) continue;
-            float2 zn = make_float2(0.f, 0.f);
-            if (!first) {
-                const float2 gij = Gs[idx];
-                const float2 zij = zzero ? make_float2(0.f, 0.f) : Zs[idx];
-                float2 c;
-                if (i < D) c = make_float2(i == j ? hp[i] : 0.f, 0.f);
-                else if (j == D) c = make_float2(corner_zp, 0.f);
-                else c = make_float2(phip[j].x, -phip[j].y);   // C[D][j] = conj(phi_prev_j)
-                zn = make_float2(zij.x + al * (gij.x - c.x), zij.y + al * (gij.y - c.y));
-                Zs[idx] = zn;
+        // The triangle is walked by its own linear index t = i (i + 1) / 2 + j (no skipped trips, no division: i from a
+        // float square root, exact below 2^24, with a one-step correction), eight elements per trip with their sixteen loads
+        // issued before the first use.
+        constexpr int PM_EPT = 8;
+        const int ntri = n * (n + 1) / 2;
+        const float2 zero2 = make_float2(0.f, 0.f);
+        for (int t0 = tid; t0 < ntri; t0 += PM_EPT * PR_THREADS) {
+            int ii[PM_EPT], jj[PM_EPT];
+            float2 gv[PM_EPT], zv[PM_EPT];
+#pragma unroll
+            for (int q = 0; q < PM_EPT; ++q) {
+                const int t = t0 + q * PR_THREADS;
+                int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                if (i * (i + 1) / 2 > t) --i;
+                if ((i + 1) * (i + 2) / 2 <= t) ++i;
+                ii[q] = i;
+                jj[q] = t - i * (i + 1) / 2;
+                const bool on = t < ntri && !first;
+                const int64_t idx = (int64_t)i * n + jj[q];
+                gv[q] = on ? Gs[idx] : zero2;
+                zv[q] = (on && !zzero) ? Zs[idx] : zero2;
             }
-            if (i == D) {
-                if (j == D) Mg[(int64_t)D * D + D] = make_float2(corner_g - inv_rho_g * zn.x, -inv_rho_g * zn.y);
-                else Mg[(int64_t)D * D + j] = make_float2(phis[j].x - inv_rho_g * zn.x, phis[j].y + inv_rho_g * zn.y);   // A[j][D] = conj(A[D][j])
-            } else {
-                const float2 a = make_float2((i == j ? hs[i] : 0.f) - inv_rho_g * zn.x, -inv_rho_g * zn.y);
-                Mg[(int64_t)i * D + j] = a;
-                if (i != j && (i >> 4) == (j >> 4)) Mg[(int64_t)j * D + i] = make_float2(a.x, -a.y);
+#pragma unroll
+            for (int q = 0; q < PM_EPT; ++q) {
+                if (t0 + q * PR_THREADS >= ntri) continue;
+                const int i = ii[q], j = jj[q];
+                const int64_t idx = (int64_t)i * n + j;
+                float2 zn = zero2;
+                if (!first) {
+                    float2 c;
+                    if (i < D) c = make_float2(i == j ? hp[i] : 0.f, 0.f);
+                    else if (j == D) c = make_float2(corner_zp, 0.f);
+                    else c = make_float2(phip[j].x, -phip[j].y);   // C[D][j] = conj(phi_prev_j)
+                    zn = make_float2(zv[q].x + al * (gv[q].x - c.x), zv[q].y + al * (gv[q].y - c.y));
+                    Zs[idx] = zn;
+                }
+                if (i == D) {
+                    if (j == D) Mg[(int64_t)D * D + D] = make_float2(corner_g - inv_rho_g * zn.x, -inv_rho_g * zn.y);
+                    else Mg[(int64_t)D * D + j] = make_float2(phis[j].x - inv_rho_g * zn.x, phis[j].y + inv_rho_g * zn.y);   // A[j][D] = conj(A[D][j])
+                } else {
+                    const float2 a = make_float2((i == j ? hs[i] : 0.f) - inv_rho_g * zn.x, -inv_rho_g * zn.y);
+                    Mg[(int64_t)i * D + j] = a;
+                    if (i != j && (i >> 4) == (j >> 4)) Mg[(int64_t)j * D + i] = make_float2(a.x, -a.y);
+                }
             }
         }
         return;
