@@ -1,5 +1,6 @@
-// lane_reduce.h -- wave-wide sums without LDS traffic (DPP row rotations + v_permlane{16,32}_swap), shared by the panel
-// tridiagonalisation (tridiag_panel.hip) and the block-reflector back-transform (wy_apply.hip).
+// lane_reduce.h -- wave-wide sums without LDS traffic (DPP row rotations + v_permlane{16,32}_swap) and two-instruction
+// complex multiply-accumulates, shared by the panel tridiagonalisation (tridiag_panel.hip) and the block-reflector
+// back-transform (wy_apply.hip).
 #pragma once
 #include "common.h"
 
@@ -42,4 +43,24 @@ __device__ __forceinline__ void pn_group_sum2(float &x, float &y) {
     x = a + b;
     y = c + d;
 }
+typedef float v2f __attribute__((ext_vector_type(2)));
+// Complex multiply-accumulate in TWO packed instructions (the scalar form takes four): v_pk_fma_f32 with op_sel picking
+// the real / imaginary half of each operand pair and neg_lo / neg_hi the sign -- the compiler folds the broadcast of the
+// first product but materialises the swapped, negated operand of the second (v_xor + v_mov), hence the asm.  The skinny
+// phases are bound by the VALU issue of ONE wave per SIMD (a wave64 instruction holds the 16-lane SIMD for 4 cycles).
+__device__ __forceinline__ v2f pk_cfma(v2f acc, v2f a, v2f b) {        // acc + a b
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "+v"(acc)
+        : "v"(a), "v"(b));
+    return acc;
+}
+__device__ __forceinline__ v2f pk_cfma_conj(v2f acc, v2f a, v2f b) {   // acc + conj(a) b
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
+        : "+v"(acc)
+        : "v"(a), "v"(b));
+    return acc;
+}
+__device__ __forceinline__ v2f pk2(float2 a) { return v2f{a.x, a.y}; }
 }  // namespace admmnet

@@ -123,26 +123,6 @@ __device__ __forceinline__ void pn_householder(float ar, float ai, float xnorm2,
     si = ident ? 0.f : -di * iden;
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-// Complex multiply-accumulate in TWO packed instructions (the scalar form takes four): v_pk_fma_f32 with op_sel picking
-// the real / imaginary half of each operand pair and neg_lo / neg_hi the sign -- the compiler folds the broadcast of the
-// first product but materialises the swapped, negated operand of the second (v_xor + v_mov), hence the asm.  The skinny
-// phases are bound by the VALU issue of ONE wave per SIMD (a wave64 instruction holds the 16-lane SIMD for 4 cycles).
-__device__ __forceinline__ v2f pk_cfma(v2f acc, v2f a, v2f b) {        // acc + a b
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "+v"(acc)
-        : "v"(a), "v"(b));
-    return acc;
-}
-__device__ __forceinline__ v2f pk_cfma_conj(v2f acc, v2f a, v2f b) {   // acc + conj(a) b
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
-        : "+v"(acc)
-        : "v"(a), "v"(b));
-    return acc;
-}
-__device__ __forceinline__ v2f pk2(float2 a) { return v2f{a.x, a.y}; }
 __device__ __forceinline__ v2f pn_lo(f32x4 a) { return v2f{a.x, a.y}; }
 __device__ __forceinline__ v2f pn_hi(f32x4 a) { return v2f{a.z, a.w}; }
 // one 16 x 16 tile (tre, tim: rows 4 g + q of column c16) in the matrix-vector product, packed FMAs over row pairs:

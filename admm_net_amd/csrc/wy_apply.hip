@@ -179,9 +179,9 @@ __global__ __launch_bounds__(64) void wy_lastcol_kernel(const float2 *__restrict
     const float2 *taus = Mg + (int64_t)D * D;
     const float *WT = Wbuf + bm * (int64_t)3 * n * n + wt_off;   // WT[c][i] = W[i][c]
     float *Vb = VT + bm * ((int64_t)n * 2 * D);
-    float2 x[4];
+    v2f xv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) x[k] = make_float2(WT[(int64_t)D * n + 1 + lane + 64 * k], 0.f);
+    for (int k = 0; k < 4; ++k) xv[k] = v2f{WT[(int64_t)D * n + 1 + lane + 64 * k], 0.f};
     float2 va[WL_BATCH][4], vb[WL_BATCH][4], ta[WL_BATCH], tb[WL_BATCH];
     auto gload = [&](float2(&buf)[WL_BATCH][4], float2(&tt)[WL_BATCH], int u0) {   // reflectors u0, u0 - 1, ...
 #pragma unroll
@@ -195,17 +195,15 @@ __global__ __launch_bounds__(64) void wy_lastcol_kernel(const float2 *__restrict
     auto apply = [&](const float2(&buf)[WL_BATCH][4], const float2(&tt)[WL_BATCH]) {
 #pragma unroll
         for (int i = 0; i < WL_BATCH; ++i) {
-            float2 d0 = cmacc(make_float2(0.f, 0.f), buf[i][0], x[0]), d1 = cmacc(make_float2(0.f, 0.f), buf[i][1], x[1]);
-            d0 = cmacc(d0, buf[i][2], x[2]);
-            d1 = cmacc(d1, buf[i][3], x[3]);
+            v2f d0 = pk_cfma_conj(v2f{0.f, 0.f}, pk2(buf[i][0]), xv[0]), d1 = pk_cfma_conj(v2f{0.f, 0.f}, pk2(buf[i][1]), xv[1]);
+            d0 = pk_cfma_conj(d0, pk2(buf[i][2]), xv[2]);
+            d1 = pk_cfma_conj(d1, pk2(buf[i][3]), xv[3]);
             float dx = pn_row16_sum(d0.x + d1.x), dy = pn_row16_sum(d0.y + d1.y);
             pn_group_sum2(dx, dy);
             const float2 sc = cmul(tt[i], make_float2(dx, dy));   // tau (v^H x)
+            const v2f nsc = v2f{-sc.x, -sc.y};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                x[k].x -= sc.x * buf[i][k].x - sc.y * buf[i][k].y;
-                x[k].y -= sc.x * buf[i][k].y + sc.y * buf[i][k].x;
-            }
+            for (int k = 0; k < 4; ++k) xv[k] = pk_cfma(xv[k], nsc, pk2(buf[i][k]));   // x -= tau (v^H x) v
         }
     };
     gload(va, ta, D - 1);
@@ -218,8 +216,8 @@ __global__ __launch_bounds__(64) void wy_lastcol_kernel(const float2 *__restrict
     float *dst = Vb + (int64_t)D * 2 * D;   // row c = 256 of the V^T image
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        dst[lane + 64 * k] = x[k].x;
-        dst[D + lane + 64 * k] = x[k].y;
+        dst[lane + 64 * k] = xv[k].x;
+        dst[D + lane + 64 * k] = xv[k].y;
     }
 }
 
