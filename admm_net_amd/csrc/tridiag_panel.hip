@@ -613,7 +613,10 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                         y.x -= acc.x + acc2.x;
                         y.y -= acc.y + acc2.y;
                     }
-                    y = cmul(tau, y);
+                    {
+                        const v2f ty = pk_cfma(v2f{0.f, 0.f}, pk2(tau), pk2(y));
+                        y = make_float2(ty.x, ty.y);
+                    }
                     mark(12);
                 }
                 preg = y;
@@ -635,12 +638,14 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
                     dot.x += sh.red2[q].x;
                     dot.y += sh.red2[q].y;
                 }
-                float2 al = cmul(tau, dot);
-                al.x *= -0.5f;
-                al.y *= -0.5f;
-                wu = pn_fma_c(sh.pu, al, hu);
+                const v2f alv = pk_cfma(v2f{0.f, 0.f}, pk2(tau), pk2(dot)) * -0.5f;
+                {
+                    const v2f t = pk_cfma(pk2(sh.pu), alv, pk2(hu));
+                    wu = make_float2(t.x, t.y);
+                }
                 if (tid < DL) {
-                    wreg = (r >= u) ? pn_fma_c(preg, al, vreg) : make_float2(0.f, 0.f);
+                    const v2f wv = pk_cfma(pk2(preg), alv, pk2(vreg));
+                    wreg = (r >= u) ? make_float2(wv.x, wv.y) : make_float2(0.f, 0.f);
                     sh.Vp[r][j] = vreg;
                     sh.Wp[r][j] = wreg;
                 }
