@@ -27,6 +27,7 @@ constexpr int DC_THREADS = 256;
 constexpr int DC_LS = 8;          // nominal leaf size (dc_leaf_start in dc_core.h spreads the remainder)
 constexpr int DC_MAXLEAF = 33;    // n <= 8 * 33 + 7
 constexpr int DC_MAXLS = 2 * DC_LS;   // a single leaf (n < 16) has up to 15 rows
+constexpr int DC_RA = 4;              // deflation rotations whose operands are loaded ahead (one L2 round trip per batch)
 constexpr int DC_FULL = 1 << 30;      // flag on a source-column index: a deflation rotation has filled all its rows
 
 // leaf scratch: Z of every leaf as [maxrows][maxrows | 1] (odd pitch: the team's row-per-lane accesses spread
@@ -299,17 +300,17 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
             // A chain of rotations (pa, pb) hands column pb on as the next pa: each thread keeps its
             // rows of that running column in a register, so the chain never round-trips through memory;
             // the other operand of every rotation is a column no earlier rotation touched, loaded
-            // four rotations ahead.
+            // DC_RA rotations ahead.
             const int nr = sh.nrot[team];
             for (int i = tl; i < nn; i += ts) {
                 float carry = 0.f;
                 int cpb = -1;
-                for (int r0 = 0; r0 < nr; r0 += 4) {
-                    DcRot rr[4];
-                    float xv[4], yv[4];
-                    int xo[4], yo[4];   // 32-bit element offsets: registers are what bounds the occupancy here
+                for (int r0 = 0; r0 < nr; r0 += DC_RA) {
+                    DcRot rr[DC_RA];
+                    float xv[DC_RA], yv[DC_RA];
+                    int xo[DC_RA], yo[DC_RA];   // 32-bit element offsets: registers are what bounds the occupancy here
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < DC_RA; ++q) {
                         rr[q] = rot[a + min(r0 + q, nr - 1)];
                         // (a column is read from memory before any rotation has written it: its rows outside its own
                         //  block are zero by definition, not by content; the flag may be set concurrently, hence masked)
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                         yv[q] = ((cb2 < n1) == (i < n1)) ? Ws[yo[q]] : 0.f;
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < DC_RA; ++q) {
                         if (r0 + q < nr) {
                             const float xi = (rr[q].pa == cpb) ? carry : xv[q], yi = yv[q];
                             Ws[xo[q]] = rr[q].c * xi + rr[q].s * yi;
