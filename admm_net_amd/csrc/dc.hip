@@ -15,6 +15,7 @@
 // registers (regenerated under the MFMA); a third n x n region takes W row-major for the consumers that want it.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 #include "dc_core.h"
@@ -48,7 +49,10 @@ struct DcShared {
     int kc[DC_MAXLEAF][2];   // per merge: non-deflated source columns with rows in the first / second block
 };
 
-template <int OCC>
+// BLK: the block-structured variant (no zero-fill, masked reads of source columns, merge products per block) -- worth
+// its extra registers and bookkeeping at n = 257 (needs the 128 registers of 4 waves per SIMD; the LDS admits 4
+// workgroups per CU there anyway); at n <= 129 the plain variant at 5 waves per SIMD is faster (cfg2: 7.5 vs 8.5 ms).
+template <int OCC, bool BLK>
 __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float *__restrict__ dT,
                                                         const float *__restrict__ eT, float *__restrict__ Wbuf,
                                                         float *__restrict__ wout, float *__restrict__ w0out,
@@ -138,8 +142,10 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
     // diagonal blocks in full, and a reader of a source column takes the rows outside that column's own block as zero
     // unless a deflation rotation has filled them (DC_FULL on the column index).  ADMMNET_DC_POISON=1 (tests) fills the
     // buffers with NaN instead, so that any read of a never-written element shows.
-    if (poison)
-        for (int64_t i = tid; i < (int64_t)2 * n * n; i += DC_THREADS) WA[i] = __int_as_float(0x7fc00000);
+    if (!BLK || poison) {
+        const float fill = BLK ? __int_as_float(0x7fc00000) : 0.f;   // (plain variant: the buffers start at zero)
+        for (int64_t i = tid; i < (int64_t)2 * n * n; i += DC_THREADS) WA[i] = fill;
+    }
     // LAPACK sstedc scales T to unit max-norm first (slascl): the deflation tests compare rho |z_j| (z normalised) with
     // 8 eps max(|d|, |z|), which means "negligible against T" only on a matrix of norm ~ 1.  Scaled here by the power
     // of two that brings max(|d|, |e|) into [0.5, 1) -- exact, so a matrix that already is of that size takes the very
@@ -317,8 +323,8 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                         const int ca = perm[a + rr[q].pa] & ~DC_FULL, cb2 = perm[a + rr[q].pb] & ~DC_FULL;
                         xo[q] = (a + ca) * n + a + i;
                         yo[q] = (a + cb2) * n + a + i;
-                        xv[q] = ((ca < n1) == (i < n1)) ? Ws[xo[q]] : 0.f;
-                        yv[q] = ((cb2 < n1) == (i < n1)) ? Ws[yo[q]] : 0.f;
+                        xv[q] = (!BLK || (ca < n1) == (i < n1)) ? Ws[xo[q]] : 0.f;
+                        yv[q] = (!BLK || (cb2 < n1) == (i < n1)) ? Ws[yo[q]] : 0.f;
                     }
 #pragma unroll
                     for (int q = 0; q < DC_RA; ++q) {
@@ -333,9 +339,11 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                 }
             }
             // both columns of a rotation now hold all nn rows (written above for every i)
-            for (int r = tl; r < nr; r += ts) {
-                atomicOr(&perm[a + rot[a + r].pa], DC_FULL);
-                atomicOr(&perm[a + rot[a + r].pb], DC_FULL);
+            if constexpr (BLK) {
+                for (int r = tl; r < nr; r += ts) {
+                    atomicOr(&perm[a + rot[a + r].pa], DC_FULL);
+                    atomicOr(&perm[a + rot[a + r].pb], DC_FULL);
+                }
             }
             {   // when the team has two lanes per root, adjacent lanes share one: each sums every other pole
                 // and one DPP swap adds the halves (one code path: G = 1 makes the swap a no-op)
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
             // of the first block (and the columns a deflation rotation filled), likewise the second -- as slaed3's two
             // GEMMs.  kl1 / kl2 list the non-deflated merged positions by that criterion, in ascending order (placed by
             // counting: deterministic), in the memory of the rotation list (dead since P3).
-            {
+            if constexpr (BLK) {
                 int *kl1 = reinterpret_cast<int *>(rot) + a, *kl2 = kl1 + NP;
                 for (int p = tl; p < k; p += ts) {
                     const int cc = cidx[a + p];
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
 #pragma unroll
                     for (int q = 0; q < 9; ++q) {
                         const int iq = i + q * cw;
-                        v[q] = (iq < nn && (full || ((col < n1) == (iq < n1)))) ? xs[iq] : 0.f;
+                        v[q] = (iq < nn && (!BLK || full || ((col < n1) == (iq < n1)))) ? xs[iq] : 0.f;
                     }
 #pragma unroll
                     for (int q = 0; q < 9; ++q)
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                     f32x16 acc0 = {0}, acc1 = {0};
                     // row tile inside one block: only that block's source columns (list), no masks; a tile that straddles
                     // the block boundary (one per merge unless n1 is a multiple of 32) takes every column and masks
-                    const bool blk1 = min(i0 + 32, mnn) <= mn1, blk2 = i0 >= mn1;
+                    const bool blk1 = BLK && min(i0 + 32, mnn) <= mn1, blk2 = BLK && i0 >= mn1;
                     const int *kl = reinterpret_cast<const int *>(rot) + ma + (blk2 ? NP : 0);
                     const int kcnt = blk1 ? sh.kc[mm][0] : (blk2 ? sh.kc[mm][1] : mk);
                     const bool listed = blk1 || blk2;
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                             const int kq = listed ? kl[kv ? ki : 0] : (kv ? ki : 0);
                             const int cc = cidx[ma + kq], col = cc & ~DC_FULL;
                             const float b_ = Ws[(ma + col) * n + ma + io];
-                            const bool ok = listed || (cc & DC_FULL) || ((col < mn1) == (io < mn1));
+                            const bool ok = !BLK || listed || (cc & DC_FULL) || ((col < mn1) == (io < mn1));
                             bv[s16] = (kv && iv && ok) ? b_ : 0.f;
                         }
 #pragma unroll
@@ -662,10 +670,11 @@ int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, 
         return ADMMNET_E_ARG;
     }
     const size_t lds = dc_lds_bytes(n);
-    // (4 workgroups per CU is what the 36 KB of LDS per workgroup admit at n = 257 anyway; compiled for 5 the kernel has
-    //  96 registers and the block-structured product below spills inside its loops: 3.34 ms -> 4.7 ms per 4096 matrices)
-    static const int occ = getenv("ADMMNET_DC_OCC") ? atoi(getenv("ADMMNET_DC_OCC")) : 4;   // tuning knob
-    auto kern = occ >= 8 ? dc_kernel<8> : occ == 6 ? dc_kernel<6> : occ == 4 ? dc_kernel<4> : dc_kernel<5>;
+    static const int env_occ = getenv("ADMMNET_DC_OCC") ? atoi(getenv("ADMMNET_DC_OCC")) : 0;   // tuning knob
+    const bool blk = n > 129 && !(getenv("ADMMNET_DC_BLOCKS") && !strcmp(getenv("ADMMNET_DC_BLOCKS"), "0"));
+    const int occ = env_occ > 0 ? env_occ : (blk ? 4 : 5);
+    auto kern = blk ? (occ >= 8 ? dc_kernel<8, true> : occ == 6 ? dc_kernel<6, true> : occ == 5 ? dc_kernel<5, true> : dc_kernel<4, true>)
+                    : (occ >= 8 ? dc_kernel<8, false> : occ == 6 ? dc_kernel<6, false> : occ == 4 ? dc_kernel<4, false> : dc_kernel<5, false>);
     ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
     static const bool timing = getenv("ADMMNET_DC_TIMING") != nullptr;   // developer aid, never on by default

@@ -51,6 +51,9 @@ constexpr int PM_HALF = 32;      // D = 256 (tridiag_panel.hip): G / Z streamed 
 constexpr int PM_LEAN = 16;      // G / Z kept as lower triangles, A built by the tridiagonalisation's own loader
                                  // (tridiag_reg.hip): only the lazy Z update streams here, 24 n^2 / 2 bytes per signal
 
+// (TRI: the D = 256 triangle walk with its 16 loads in flight compiled in -- 98 VGPRs; the other instance keeps the 54
+//  registers and 8 waves per SIMD the lean D <= 128 stream wants)
+template <bool TRI>
 __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
     int D, int mode, const float *__restrict__ lw, const float *__restrict__ lw_prev,
     const float2 *__restrict__ y, const float2 *__restrict__ bsym, const float *__restrict__ sigma,
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
     const float corner_g = lw[S_CORNER_G], inv_rho_g = lw[S_INV_RHO_G];
     const float corner_zp = first ? 0.f : lw_prev[S_CORNER_Z];
     float2 *Mg = Mbuf + s * ((int64_t)D * D + D + 1);
-    if (mode & PM_HALF) {
+    if (TRI && (mode & PM_HALF)) {
         // Lower triangle only (G, Z and C are Hermitian; row D = the arrow row lies in it): half the G / Z streams,
         // about half the image.  Entries inside a diagonal 16-block also write their mirror, the arrow COLUMN of the
         // image is the conjugate of the arrow row.
@@ -318,7 +321,8 @@ int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2
     if (lean) mode |= (D > 128) ? PM_HALF : PM_LEAN;
     const int cur = k & 1, prv = cur ^ 1;
     const size_t lds = sizeof(float2) * 2 * D + sizeof(float) * (3 * D + kHid + 8);
-    hipLaunchKernelGGL(prep_kernel, dim3((unsigned)nb), dim3(PR_THREADS), lds, st, D, mode, lw, lwp,
+    auto kern = (mode & PM_HALF) ? prep_kernel<true> : prep_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(PR_THREADS), lds, st, D, mode, lw, lwp,
                        y + b0 * D, b + b0 * D, sigma + b0, ws.G + b0 * (int64_t)n * n,
                        ws.Z + b0 * (int64_t)n * n, ws.phi[prv] + b0 * D, ws.h[prv] + b0 * D, ws.alpha + b0,
                        ws.phi[cur] + b0 * D, ws.h[cur] + b0 * D, ws.Mbuf);
