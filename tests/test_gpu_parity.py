@@ -235,6 +235,21 @@ def test_forward_with_small_and_large_measurements(dev, geom, yscale):
     assert rel(phi, o64) <= 3 * rel(o32, o64) + 1e-5
 
 
+def test_forward_is_bitwise_reproducible(dev):
+    """Same inputs, same bits: the D&C places by counting (no append-by-atomic), the batch mean is a fixed-order float64
+    sum, no kernel accumulates through floating-point atomics."""
+    Nb, Nd, K, B = 16, 16, 4, 24
+    sd = R.make_weights(Nb, Nd, K, seed=11, head=True, perturb=0.3)
+    m = A.ADMMNet(M=Nb, N=Nd, num_layers=K).eval()
+    m.load_state_dict(sd, strict=True)
+    y, b, s, _ = synth.make_batch(B, Nb, Nd, seed=23)
+    ty, tb, ts = torch.from_numpy(y).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(s).to(dev)
+    outs = [tuple(o.cpu().numpy().copy() for o in m(ty, tb, ts)) for _ in range(3)]
+    for o in outs[1:]:
+        for a0, a1 in zip(outs[0], o):
+            assert np.array_equal(a0, a1)
+
+
 def test_chunking_is_invisible(dev):
     """Eigensolver work chunks (workspace reuse) must not change anything."""
     Nb, Nd, K, B = 4, 5, 3, 37
