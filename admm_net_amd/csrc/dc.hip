@@ -300,6 +300,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
             atomicAdd(&tstat[4 * min(lvl, 5) + 1], (unsigned int)k);
             atomicAdd(&tstat[4 * min(lvl, 5) + 2], (unsigned int)sh.nrot[team]);
             atomicAdd(&tstat[4 * min(lvl, 5) + 3], 1u);
+            if (sh.conf[team]) atomicAdd(&tacc[56 + min(lvl, 5)], 1u);   // merges left to the serial scan
         }
         // P3: deflation rotations on the source columns (thread-private rows i) + secular roots
         if (act) {
@@ -698,9 +699,9 @@ int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, 
         for (int i = 0; i < 12; ++i) fprintf(stderr, "   %-16s %10.0f\n", nm[i], (double)h[i] / (double)nb);
         for (int l = 0; l < 6; ++l)
             if (h[64 + 4 * l + 3])
-                fprintf(stderr, "   level %d merges: mean size %.1f, non-deflated %.1f, rotations %.1f\n", l,
+                fprintf(stderr, "   level %d merges: mean size %.1f, non-deflated %.1f, rotations %.1f, left to the serial scan %.3f\n", l,
                         (double)h[64 + 4 * l] / h[64 + 4 * l + 3], (double)h[64 + 4 * l + 1] / h[64 + 4 * l + 3],
-                        (double)h[64 + 4 * l + 2] / h[64 + 4 * l + 3]);
+                        (double)h[64 + 4 * l + 2] / h[64 + 4 * l + 3], (double)h[56 + l] / h[64 + 4 * l + 3]);
         for (int l = 0; l < 6; ++l) {
             fprintf(stderr, "   level %d:", l);
             for (int q = 0; q < 8; ++q) fprintf(stderr, " %8.0f", (double)h[16 + 8 * l + q] / (double)nb);   // P1..P7, GEMM
