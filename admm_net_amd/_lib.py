@@ -61,6 +61,7 @@ SYMBOLS = {
                                       c_void_p, c_void_p]),
     "admmnet_profile_enable": (c_int32, [c_int32]),
     "admmnet_profile_read": (c_int32, [c_void_p, c_void_p, c_int32]),
+    "admmnet_profile_dropped": (c_int64, []),
 }
 
 

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -21,26 +22,50 @@ void set_error(const char *fmt, ...) {
 }
 
 // ---- profiler -------------------------------------------------------------------
-static const int kProfMax = 8192;
-static bool g_prof_on = false;
-static int g_prof_n = 0;
-static hipEvent_t g_prof_ev[kProfMax][2];
-static int g_prof_class[kProfMax];
-static int g_prof_created = 0;
+// Event pairs live in a pool that grows with the number of scopes recorded since the last read (the bench records
+// ~600 scopes per cfg3 step; an earlier fixed pool of 8192 silently dropped everything after step 13).  A scope is
+// only ever dropped when an event cannot be created; drops are counted and reported by admmnet_profile_dropped().
+struct ProfState {
+    std::mutex mu;
+    bool on = false;
+    std::vector<hipEvent_t> ev0, ev1;   // created events (reused across reads)
+    std::vector<int> kclass;            // class of the scopes recorded since the last read
+    int64_t dropped = 0;
+};
+static ProfState &prof() {
+    static ProfState p;
+    return p;
+}
+static const size_t kProfHardCap = (size_t)1 << 22;   // 4 M scopes between two reads: a runaway guard, not a budget
 
 ProfScope::ProfScope(int kclass, hipStream_t s) : slot(-1), st(s) {
-    if (!g_prof_on || g_prof_n >= kProfMax) return;
-    slot = g_prof_n++;
-    if (slot >= g_prof_created) {
-        (void)hipEventCreate(&g_prof_ev[slot][0]);
-        (void)hipEventCreate(&g_prof_ev[slot][1]);
-        g_prof_created = slot + 1;
+    ProfState &p = prof();
+    if (!p.on) return;
+    std::lock_guard<std::mutex> lk(p.mu);
+    const size_t i = p.kclass.size();
+    if (i >= p.ev0.size()) {
+        hipEvent_t a, b;
+        if (i >= kProfHardCap || hipEventCreate(&a) != hipSuccess) {
+            ++p.dropped;
+            return;
+        }
+        if (hipEventCreate(&b) != hipSuccess) {
+            (void)hipEventDestroy(a);
+            ++p.dropped;
+            return;
+        }
+        p.ev0.push_back(a);
+        p.ev1.push_back(b);
     }
-    g_prof_class[slot] = kclass;
-    (void)hipEventRecord(g_prof_ev[slot][0], st);
+    p.kclass.push_back(kclass);
+    slot = (int)i;
+    (void)hipEventRecord(p.ev0[i], st);
 }
 ProfScope::~ProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_prof_ev[slot][1], st);
+    if (slot < 0) return;
+    ProfState &p = prof();
+    std::lock_guard<std::mutex> lk(p.mu);
+    (void)hipEventRecord(p.ev1[slot], st);
 }
 
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -539,9 +564,18 @@ int admmnet_eigh_c64(int32_t n, int64_t B, const void *A, float *w, void *V, voi
 }
 
 int admmnet_profile_enable(int32_t on) {
-    g_prof_on = on != 0;
-    g_prof_n = 0;
+    ProfState &p = prof();
+    std::lock_guard<std::mutex> lk(p.mu);
+    p.on = on != 0;
+    p.kclass.clear();
+    p.dropped = 0;
     return ADMMNET_OK;
+}
+
+int64_t admmnet_profile_dropped(void) {
+    ProfState &p = prof();
+    std::lock_guard<std::mutex> lk(p.mu);
+    return p.dropped;
 }
 
 int admmnet_profile_read(double *ms_total, int64_t *launches, int32_t nclasses) {
@@ -550,14 +584,16 @@ int admmnet_profile_read(double *ms_total, int64_t *launches, int32_t nclasses) 
         return ADMMNET_E_ARG;
     }
     for (int i = 0; i < nclasses; ++i) { ms_total[i] = 0.0; launches[i] = 0; }
-    for (int i = 0; i < g_prof_n; ++i) {
-        ADMM_HIP(hipEventSynchronize(g_prof_ev[i][1]));
+    ProfState &p = prof();
+    std::lock_guard<std::mutex> lk(p.mu);
+    for (size_t i = 0; i < p.kclass.size(); ++i) {
+        ADMM_HIP(hipEventSynchronize(p.ev1[i]));
         float ms = 0.f;
-        ADMM_HIP(hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]));
-        ms_total[g_prof_class[i]] += ms;
-        launches[g_prof_class[i]] += 1;
+        ADMM_HIP(hipEventElapsedTime(&ms, p.ev0[i], p.ev1[i]));
+        ms_total[p.kclass[i]] += ms;
+        launches[p.kclass[i]] += 1;
     }
-    g_prof_n = 0;
+    p.kclass.clear();
     return ADMMNET_OK;
 }
 

@@ -110,10 +110,26 @@ def save_checkpoint(path, model, optimizer=None, scheduler=None, epoch=0, best_v
     }, path)
 
 
+def _numpy_scalar_globals():
+    """What pickle needs to rebuild a numpy scalar (``np.float64`` ...): train.py:279-282 appends ``np.mean(...)`` results
+    to ``history['tau_rmse']`` / ``['f_rmse']`` and saves ``history`` in the checkpoint (train.py:306-314).  These three
+    reconstruct plain numbers and run nothing from the file, so the loader stays ``weights_only=True``."""
+    try:
+        from numpy._core import multiarray as ma          # numpy >= 2
+    except ImportError:                                    # numpy 1.x
+        from numpy.core import multiarray as ma
+    kinds = {type(np.dtype(t)) for t in ("float64", "float32", "float16", "int64", "int32", "bool", "complex64",
+                                         "complex128")}
+    return [ma.scalar, np.dtype] + sorted(kinds, key=lambda k: k.__name__)
+
+
 def load_checkpoint(path, model, optimizer=None, scheduler=None, map_location="cpu"):
-    """train.py:137-145 (resume) / main_for_net.py:100-101 (inference).  Checkpoints are dicts of tensors and plain
-    Python values, so the safe loader is enough; returns the dict."""
-    ckpt = torch.load(path, map_location=map_location, weights_only=True)
+    """train.py:137-145 (resume) / main_for_net.py:100-101 (inference).  Checkpoints written by train.py / trainPhi.py
+    are dicts of tensors, plain Python values and numpy scalars (the RMSE history): the no-code loader with numpy
+    scalar reconstruction allowed reads them; anything else in the file is refused (never ``weights_only=False``).
+    Returns the dict."""
+    with torch.serialization.safe_globals(_numpy_scalar_globals()):
+        ckpt = torch.load(path, map_location=map_location, weights_only=True)
     model.load_state_dict(ckpt["model_state_dict"])
     if optimizer is not None and ckpt.get("optimizer_state_dict"):
         optimizer.load_state_dict(ckpt["optimizer_state_dict"])

@@ -264,6 +264,27 @@ def test_chunking_is_invisible(dev):
     assert torch.equal(m(*args).cpu(), ref)
 
 
+@pytest.mark.parametrize("grid", [(16, 16), (12, 16)])
+def test_chunking_is_invisible_on_the_large_matrix_pipeline(dev, grid):
+    """The same for the D > 128 pipeline (half-image prep, panel tridiagonalisation with its per-chunk T factors and
+    hand-over tiles, D&C buffers, block-reflector back-transform, resident-tile rebuild): the `b0 * n * n` offsets of
+    the lower-triangle G / Z state and the reuse of every chunk buffer across chunks.  B = 5 at chunk = 2 is three
+    chunks, the last one ragged; head outputs included (ADMMNet)."""
+    Nb, Nd = grid
+    K, B = 3, 5
+    torch.manual_seed(8)
+    m = A.ADMMNet(M=Nb, N=Nd, num_layers=K).eval()
+    y, b, s, _ = synth.make_batch(B, Nb, Nd, seed=4)
+    args = [torch.from_numpy(v).to(dev) for v in (y, b, s)]
+    m.chunk = 0
+    ref = [o.cpu() for o in m(*args)]
+    m.chunk = 2
+    m._ws = None
+    got = [o.cpu() for o in m(*args)]
+    for a0, a1 in zip(ref, got):
+        assert torch.equal(a0, a1)
+
+
 def test_layer_api_and_sharded_single_rank(dev):
     Nb, Nd, K, B = 6, 6, 4, 20
     torch.manual_seed(4)

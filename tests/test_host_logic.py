@@ -602,6 +602,44 @@ def test_checkpoint_roundtrip_in_train_py_format(tmp_path):
     assert torch.equal(m3.gLayers[1].value_net[0].weight, m.gLayers[1].value_net[0].weight)
 
 
+def test_checkpoint_written_the_way_train_py_writes_it_loads(tmp_path):
+    """A checkpoint as train.py itself produces it: ``config`` = the dict of train.py:17-39 (strings / numbers) and
+    ``history`` holding the ``np.mean(...)`` results train.py:279-282 appends (numpy scalars, which a bare
+    ``weights_only=True`` load refuses).  The loader must read it without executing anything from the file, and must
+    still refuse a file that carries an arbitrary object."""
+    from admm_net_amd import harness
+    torch.manual_seed(5)
+    m = A.ADMMNet(M=4, N=4, L=3, num_layers=2)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-3)
+    sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2)
+    config = {"data_dir": "data/fixSNR20L3", "batch_size": 256, "num_workers": 4, "num_layers": 10, "M": 10, "N": 10,
+              "L_max": 3, "hidden_dim": 128, "epochs": 100, "lr": 1e-3, "weight_decay": 1e-3, "device": "cpu",
+              "checkpoint_dir": "checkpoints/run", "log_dir": "logs/run"}
+    history = {"train_loss": [0.9, 0.7], "val_loss": [1.0, 0.8], "lr": [1e-3, 9.7e-4],
+               "tau_rmse": [np.mean([0.11, 0.13]), np.mean([0.09, 0.10])],        # np.float64, as train.py:279-282
+               "f_rmse": [np.mean([0.21]), np.mean(np.float32([0.19, 0.2]))]}     # np.float64 / np.float32
+    path = tmp_path / "best_model.pth"
+    harness.save_checkpoint(path, m, opt, sch, epoch=1, best_val_loss=float(history["val_loss"][-1]), config=config,
+                            history=history)
+    with pytest.raises(Exception):
+        torch.load(path, weights_only=True)            # the plain safe loader stops at numpy's scalar constructor
+    m2 = A.ADMMNet(M=4, N=4, L=3, num_layers=2)
+    ck = harness.load_checkpoint(path, m2)
+    assert ck["config"] == config
+    assert [float(v) for v in ck["history"]["tau_rmse"]] == [float(v) for v in history["tau_rmse"]]
+    assert isinstance(ck["history"]["f_rmse"][1], np.float32)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+
+    class Payload:                                     # anything that is not a tensor / number / numpy scalar
+        def __reduce__(self):
+            return (print, ("executed from a checkpoint",))
+    bad = tmp_path / "bad.pth"
+    torch.save({"model_state_dict": m.state_dict(), "history": {"x": Payload()}}, bad)
+    with pytest.raises(Exception):
+        harness.load_checkpoint(bad, m2)
+
+
 def test_time_admm_writes_the_reference_file_format(tmp_path):
     """test_time_admm.py:104-110: np.savetxt of one wall time per run -> the format of results/time/time.txt."""
     from admm_net_amd import harness
