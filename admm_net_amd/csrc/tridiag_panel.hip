@@ -84,9 +84,6 @@ __device__ __forceinline__ float pn_pair_sum(float x) {
     return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
 }
 __device__ __forceinline__ float pn_wave_sum(float x) { return pn_group_sum(pn_row16_sum(x)); }
-__device__ __forceinline__ float pn_readlane(float x, int l) {   // (uniform result)
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
-}
 
 __device__ __forceinline__ float2 pn_fma_c(float2 acc, float2 a, float2 b) {      // acc + a b
     acc.x = fmaf(a.x, b.x, fmaf(-a.y, b.y, acc.x));
@@ -782,653 +779,6 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
     }
 }
 
-
-// =====================================================================================================================
-// Two-barrier form of the reflector step (round 3).  Same data layout, same panel organisation, same outputs; what
-// changes is the dependency chain of ONE reflector, which is what the kernel's time is made of (phase timers, round 2:
-// four barrier-separated latency chains, ~10 k cycles per reflector with the matrix cores busy 10 %):
-//   phase I   (every wave)  reflector scalars from the norm partials (redundantly per wave: no broadcast, no barrier),
-//             the panel dots W^H v, V^H v INCLUDING their unit-row term, then y = M v straight away -- the unit entry of
-//             v is patched in from registers, the rest of v was stored one phase earlier -- and the wave's share of
-//             v^H M v from the row-form partials it already holds
-//   --- barrier ---
-//   phase II  row waves: y assembled, panel corrections, p = tau y, w = p - (tau / 2)(p^H v) v with
-//                 p^H v = conj(tau) (v^H M v - 2 Re sum conj(W_k^H v)(V_k^H v))          (no reduction over p)
-//             and w[u] = the unit row's entry recomputed by every row wave with one 64-lane sum (no broadcast), so the
-//             NEXT column can be brought up to date, its norm partials taken and the next v stored in the same phase;
-//             the other waves: look-ahead of the column after next (reflectors < j) + column j of the T factor
-//   --- barrier ---
-// The look-ahead is two columns deep because column j + 1 is consumed in the phase that produces reflector j: at step j
-//     x_{j+1} = L_{j+1} - [v_{j-1} conj(w_{j-1}[c]) + w_{j-1} conj(v_{j-1}[c])] - [v_j conj(w_j[c]) + w_j conj(v_j[c])],
-// L_{j+1} = A[:, j+1] corrected with the reflectors < j - 1 (written during step j - 1), c = the column's own row.
-template <int NT>
-struct PnShared2 {
-    static constexpr int DL = 16 * NT, NW = NT / 2;
-    float2 Vp[DL][PN_PITCH];       // panel reflectors (unnormalised), row r = local M-row
-    float2 Wp[DL][PN_PITCH];       // panel w vectors
-    float2 Ap[DL][PN_PITCH];       // block column p of the panel-start matrix (the 16 columns the panel reduces)
-    float2 colbuf[DL];             // the arrow: column of the prologue reflector
-    float2 vbuf[DL];               // current column below its unit position, zero at and above it (the unit entry of the
-                                   // reflector lives in registers: every wave derives it itself)
-    float2 Lbuf[2][DL];            // look-ahead columns (see above), slot = column parity
-    float2 unext[DL];              // column 16 (p + 1) of the panel-start matrix (rows >= it): the unit column of step j = 15
-    float2 yrow[DL];               // row-form part of M v (written by the owner wave of each block row)
-    float2 ycol[NW][DL];           // column-form partials per wave
-    float2 g[32];                  // g[jj] = W_jj^H v, g[16 + jj] = V_jj^H v
-    float2 Gp[16][16];             // Gp[k][i] = V_k^H v_i (k < i): strict upper triangle of the panel's Gram matrix
-    float2 Tl[16][16];             // T factor of the panel's block reflector, built one column per reflector
-    float dbuf[DL + 4], ebuf[DL + 4];
-    float2 taubuf[DL];
-    float red[8];                  // |x|^2 partials of the row waves
-    float qpart[8];                // v^H M v partials of the tile waves
-    float2 alpha;
-};
-
-template <int NT, bool HEAD, bool TIMING>
-__global__ __launch_bounds__(32 * NT, 2) void tridiag_panel2_kernel(float2 *__restrict__ Mbuf, float *__restrict__ dT,
-                                                                    float *__restrict__ eT, float2 *__restrict__ Tfac,
-                                                                    float2 *__restrict__ Tail, int pstop, int zfill,
-                                                                    unsigned long long *__restrict__ tdbg) {
-    static_assert(NT % 4 == 0 && NT <= 16 && (HEAD == (NT == 16)), "stage geometry");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Shared = PnShared2<NT>;
-    Shared &sh = *reinterpret_cast<Shared *>(smem);
-    constexpr int D = PN_D, n = D + 1;
-    constexpr int DL = 16 * NT, NW = NT / 2, RW = DL / 64, THREADS = 64 * NW;   // RW row waves, NW tile waves
-    constexpr int R0 = D - DL, P0 = 16 - NT;                                    // first M-row / panel of this stage
-    constexpr bool ALLW = (NT == 16);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c16_0 = lane & 15, g_0 = lane >> 4;
-    int c16 = c16_0, g = g_0;
-    int IA = wave, IB = NT - 1 - wave;
-    const int64_t bm = blockIdx.x;
-    float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
-    float *dcol = dT + bm * n, *ecol = eT + bm * n;
-    float2 *tail = Tail + bm * (PN_TAIL_TILES * 256);
-
-    // ---- load the Hermitian half into the accumulator layout (as tridiag_panel_kernel)
-    f32x4 tr[NT + 1], ti[NT + 1];
-#pragma unroll
-    for (int s = 0; s < NT + 1; ++s) {
-        PN_SLOT_IJ(s, I, J)
-        if constexpr (HEAD) {
-            const float2 *src = Mg + (int64_t)(16 * I + 4 * g) * D + 16 * J + c16;
-            const float2 e0 = src[0], e1 = src[D], e2 = src[2 * D], e3 = src[3 * D];
-            const float dsc = (I == J) ? 0.5f : 1.0f;   // diagonal tiles at half value (see tridiag_panel_kernel)
-            tr[s] = f32x4{e0.x, e1.x, e2.x, e3.x} * dsc;
-            ti[s] = f32x4{e0.y, e1.y, e2.y, e3.y} * dsc;
-            if (J == 0 && c16 == 0) {   // column 0 of M: the unit column of the prologue reflector
-                float2 *dst = &sh.unext[16 * I + 4 * g];
-                dst[0] = e0; dst[1] = e1; dst[2] = e2; dst[3] = e3;
-            }
-        } else {
-            const float2 e0 = tail[pn_tail_at(I, J, 0, lane)], e1 = tail[pn_tail_at(I, J, 1, lane)],
-                         e2 = tail[pn_tail_at(I, J, 2, lane)], e3 = tail[pn_tail_at(I, J, 3, lane)];
-            tr[s] = f32x4{e0.x, e1.x, e2.x, e3.x};
-            ti[s] = f32x4{e0.y, e1.y, e2.y, e3.y};
-            if (J == 0) {
-                const float cs = (I == 0) ? 2.0f : 1.0f;
-                float2 *dst = &sh.Ap[16 * I + 4 * g][c16];
-                dst[0] = make_float2(e0.x * cs, e0.y * cs);
-                dst[PN_PITCH] = make_float2(e1.x * cs, e1.y * cs);
-                dst[2 * PN_PITCH] = make_float2(e2.x * cs, e2.y * cs);
-                dst[3 * PN_PITCH] = make_float2(e3.x * cs, e3.y * cs);
-            }
-            if (J == 1 && c16 == 0) {   // column 16: the unit column of the first panel's last step
-                const float cs = (I == 1) ? 2.0f : 1.0f;
-                float2 *dst = &sh.unext[16 * I + 4 * g];
-                dst[0] = make_float2(e0.x * cs, e0.y * cs);
-                dst[1] = make_float2(e1.x * cs, e1.y * cs);
-                dst[2] = make_float2(e2.x * cs, e2.y * cs);
-                dst[3] = make_float2(e3.x * cs, e3.y * cs);
-            }
-        }
-    }
-    float corner = 0.f;
-    if constexpr (HEAD) corner = Mg[(int64_t)D * D + D].x;
-    for (int i = tid; i < DL * PN_PITCH; i += THREADS) {
-        (&sh.Vp[0][0])[i] = make_float2(0.f, 0.f);
-        (&sh.Wp[0][0])[i] = make_float2(0.f, 0.f);
-    }
-    for (int i = tid; i < 256; i += THREADS) {
-        (&sh.Gp[0][0])[i] = make_float2(0.f, 0.f);
-        (&sh.Tl[0][0])[i] = make_float2(0.f, 0.f);
-    }
-    if (tid < 32) sh.g[tid] = make_float2(0.f, 0.f);
-    if (tid < 8) sh.qpart[tid] = 0.f;
-    if constexpr (HEAD)
-        if (tid < D) sh.colbuf[tid] = Mg[(int64_t)D * D + tid];
-    __syncthreads();
-
-    const int r = tid;   // row owned by the threads of the row waves
-    unsigned long long tmark = TIMING ? __builtin_amdgcn_s_memtime() : 0ull, tacc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto mark = [&](int id) {
-        if constexpr (TIMING) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            tacc[id] += t - tmark;
-            tmark = t;
-        }
-    };
-
-    // The column of step (p, j) enters the chain: d, alpha, |x|^2 partials, v below the unit row.  x is valid for rows
-    // >= c = 16 p + j.
-    auto enter_column = [&](float2 x, int c) {
-        const int u = c + 1;
-        sh.vbuf[r] = (r > u) ? x : make_float2(0.f, 0.f);
-        if (r == c) sh.dbuf[u] = x.x;
-        if (r == u) sh.alpha = x;
-        float pn = (r > u) ? (x.x * x.x + x.y * x.y) : 0.f;
-        pn = pn_wave_sum(pn);
-        if (lane == 0) sh.red[wave] = pn;
-    };
-
-    for (int p = HEAD ? -1 : 0; p < NT; ++p) {
-        // ---- panel prologue: empty panel, column 0 enters, L_1 = A[:, 1]
-        if (p >= 0) {
-            for (int i = tid; i < DL * 16; i += THREADS) {
-                sh.Vp[i >> 4][i & 15] = make_float2(0.f, 0.f);
-                sh.Wp[i >> 4][i & 15] = make_float2(0.f, 0.f);
-            }
-            if (tid < 32) sh.g[tid] = make_float2(0.f, 0.f);
-        }
-        if (tid < DL) {
-            if (HEAD && p < 0) {
-                if (r == 0) sh.dbuf[0] = corner;
-                enter_column(sh.colbuf[r], -1);
-            } else {
-                enter_column(sh.Ap[r][0], 16 * p);
-                sh.Lbuf[1][r] = sh.Ap[r][1];
-            }
-        }
-        __syncthreads();   // (alpha)
-        for (int j = (p < 0) ? 15 : 0; j < 16; ++j) {
-            const int c = 16 * p + j, u = c + 1;
-            if (u >= DL) break;        // c = DL - 1: only d[D] was due (uniform)
-            c16 = c16_0;
-            g = g_0;
-            asm volatile("" : "+v"(c16), "+v"(g));
-            {
-                int wv = wave;
-                asm volatile("" : "+s"(wv));
-                IA = wv;
-                IB = NT - 1 - wv;
-            }
-            const int J0 = u >> 4;
-            // ================= phase I: y_x = M x, panel dots, reflector scalars =================
-            // x = the column below its unit row (vbuf; zero at and above it).  The unit entry hu of v is NOT needed here:
-            //     M v = M x + hu M[:, u],   v^H M v = x^H M x + 2 Re(conj(hu) (M x)[u]) + |hu|^2 M[u][u],
-            // and column u of the panel-start matrix is in LDS (Ap, or unext for the first column of the next block), so the
-            // tile work starts straight behind the barrier and the scalar chain (rsq, rcp, Newton steps: ~40 dependent
-            // instructions) is scheduled into its shadow.  H = I needs no branch: x = 0 gives y = 0, w = 0.
-            float2 tau, hu;
-            float sabs;   // |tau|: the products below are formed as (s a)(s b), never as s^2 (a b) -- v^H M v is of the order
-                          // |M|^3 and leaves the float range for matrices of norm 1e-17 long before its scaled form does
-            {
-                float xn2;
-                if constexpr (RW == 4) xn2 = (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
-                else if constexpr (RW == 2) xn2 = sh.red[0] + sh.red[1];
-                else xn2 = sh.red[0];
-                const float2 alpha = sh.alpha;
-                // clarfg with the reflector left unnormalised: v = (alpha - beta, x), H = I - tau v v^H,
-                //   beta = -sign(ar) |(alpha, x)|,  tau = -(alpha - beta) / (beta |alpha - beta|^2)
-                // (= LAPACK's tau / |alpha - beta|^2); branch-free, power-of-two pre / post scaling outside the normal range
-                const float ar = alpha.x, ai = alpha.y;
-                const bool ident = (xn2 == 0.f && ai == 0.f);
-                const float q2 = ar * ar + ai * ai + xn2;
-                const float sc = (q2 < 1e-30f) ? 0x1p+64f : ((q2 > 1e30f) ? 0x1p-64f : 1.0f);
-                const float ps = (q2 < 1e-30f) ? 0x1p-32f : ((q2 > 1e30f) ? 0x1p+32f : 1.0f);
-                const float q2s = ident ? 1.0f : q2 * sc;
-                const float nrm = q2s * rsqrt_nr1(q2s) * ps;
-                const float bt = -sign_of(nrm, ar);
-                const float dr = ar - bt, di = ai;
-                // (two independent reciprocals, 1 / beta and 1 / |d|^2, rather than one of the product: the product leaves
-                //  the float range for matrices of norm 1e-17 or 1e16, which the scale-invariance test feeds)
-                const float ib = recip_nr(bt), iden = recip_nr(dr * dr + di * di);
-                tau = ident ? make_float2(0.f, 0.f) : make_float2(-(dr * iden) * ib, -(di * iden) * ib);
-                hu = ident ? make_float2(0.f, 0.f) : make_float2(dr, di);
-                sabs = ident ? 0.f : fabsf(ib) * ((dr * dr + di * di) * rsqrt_nr1(dr * dr + di * di)) * iden;
-                if (tid == 0) {
-                    sh.ebuf[u] = ident ? ar : bt;
-                    sh.taubuf[u] = tau;
-                }
-            }
-            {
-                v2f Ar01, Ar23, Ai01, Ai23, Br01, Br23, Bi01, Bi23;   // x at the rows of block rows IA / IB (planar pairs)
-                {
-                    const float2 *va = &sh.vbuf[16 * IA + 4 * g], *vb = &sh.vbuf[16 * IB + 4 * g];
-                    const float2 a0 = va[0], a1 = va[1], a2 = va[2], a3 = va[3];
-                    const float2 b0 = vb[0], b1 = vb[1], b2 = vb[2], b3 = vb[3];
-                    Ar01 = v2f{a0.x, a1.x}; Ar23 = v2f{a2.x, a3.x}; Ai01 = v2f{a0.y, a1.y}; Ai23 = v2f{a2.y, a3.y};
-                    Br01 = v2f{b0.x, b1.x}; Br23 = v2f{b2.x, b3.x}; Bi01 = v2f{b0.y, b1.y}; Bi23 = v2f{b2.y, b3.y};
-                }
-                const v2f z2 = v2f{0.f, 0.f};
-                v2f PAr01 = z2, PAr23 = z2, PAi01 = z2, PAi23 = z2, PBr01 = z2, PBr23 = z2, PBi01 = z2, PBi23 = z2;
-#pragma unroll
-                for (int JQ = 0; JQ < NT; JQ += 4) {
-                    if (JQ + 3 >= J0 && JQ <= IB) {   // (uniform) four block columns per pass: one joint lane reduction
-                        float cx[4], cy[4];
-                        float2 vJq[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) vJq[k] = sh.vbuf[16 * (JQ + k) + c16];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int J = JQ + k;
-                            v2f Cr = z2, Ci = z2;
-                            if (J >= J0 && J <= IB) {   // (uniform)
-                                const float2 vJ = vJq[k];
-                                pn_tile_mv(tr[J], ti[J], vJ, Br01, Br23, Bi01, Bi23, PBr01, PBr23, PBi01, PBi23, Cr, Ci);
-                                if (J <= IA)
-                                    pn_tile_mv(tr[NT - J], ti[NT - J], vJ, Ar01, Ar23, Ai01, Ai23, PAr01, PAr23, PAi01,
-                                               PAi23, Cr, Ci);
-                            }
-                            cx[k] = Cr.x + Cr.y;
-                            cy[k] = Ci.x + Ci.y;
-                        }
-                        float tx, ty;
-                        pn_quad_group_sum2(cx, cy, tx, ty);
-                        const int Jl = JQ + ((g & 1) << 1) + (g >> 1);
-                        if (Jl >= J0 && Jl <= IB) sh.ycol[wave][16 * Jl + c16] = make_float2(tx, ty);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                mark(1);
-                // the wave's share of x^H M x = 2 Re sum over its tiles of x_I^H (T x_J) (diagonal tiles are held at half
-                // value and run both forms, off-diagonal ones contribute a conjugate pair): from the row-form partials
-                {   // (scaled: |tau| (x^H M x), see sabs)
-                    const v2f sv = v2f{sabs, sabs};
-                    v2f s2 = Ar01 * (PAr01 * sv);
-                    s2 = __builtin_elementwise_fma(Ar23, PAr23 * sv, s2);
-                    s2 = __builtin_elementwise_fma(Ai01, PAi01 * sv, s2);
-                    s2 = __builtin_elementwise_fma(Ai23, PAi23 * sv, s2);
-                    s2 = __builtin_elementwise_fma(Br01, PBr01 * sv, s2);
-                    s2 = __builtin_elementwise_fma(Br23, PBr23 * sv, s2);
-                    s2 = __builtin_elementwise_fma(Bi01, PBi01 * sv, s2);
-                    s2 = __builtin_elementwise_fma(Bi23, PBi23 * sv, s2);
-                    const float sq = pn_wave_sum(s2.x + s2.y);
-                    if (lane == 0) sh.qpart[wave] = 2.0f * sq;
-                }
-                // row sums of the row-form partials (as tridiag_panel_kernel)
-                if constexpr (ALLW) {
-                    const bool b3_ = c16 & 8, b2_ = c16 & 4, b1_ = c16 & 2, b0_ = c16 & 1;
-                    float total;
-                    const float vB[8] = {PBr01.x, PBi01.x, PBr01.y, PBi01.y, PBr23.x, PBi23.x, PBr23.y, PBi23.y};
-                    if (IA >= J0) {
-                        const float vA[8] = {PAr01.x, PAi01.x, PAr01.y, PAi01.y, PAr23.x, PAi23.x, PAr23.y, PAi23.y};
-                        float w8[8], w4[4], w2[2];
-#pragma unroll
-                        for (int m = 0; m < 8; ++m) w8[m] = pn_keep_add<0x140>(b3_, vB[m], vA[m]);
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) w4[m] = pn_keep_add<0x141>(b2_, w8[m], w8[m + 4]);
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) w2[m] = pn_keep_add<0x1B>(b1_, w4[m], w4[m + 2]);
-                        total = pn_keep_add<0xB1>(b0_, w2[0], w2[1]);
-                        const int q = (c16 >> 1) & 3, I = b3_ ? IA : IB;
-                        reinterpret_cast<float *>(&sh.yrow[16 * I + 4 * g + q])[c16 & 1] = total;
-                    } else if (IB >= J0) {
-                        float w4[4], w2[2];
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) w4[m] = pn_keep_add<0x141>(b2_, vB[m], vB[m + 4]);
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) w2[m] = pn_keep_add<0x1B>(b1_, w4[m], w4[m + 2]);
-                        total = pn_keep_add<0xB1>(b0_, w2[0], w2[1]);
-                        total += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, total), 0x128,
-                                                                                        0xF, 0xF, false));
-                        const int q = (c16 >> 1) & 3;
-                        if (!b3_) reinterpret_cast<float *>(&sh.yrow[16 * IB + 4 * g + q])[c16 & 1] = total;
-                    }
-                } else {
-                    if (IB >= J0) {
-                        float2 P[4] = {make_float2(PBr01.x, PBi01.x), make_float2(PBr01.y, PBi01.y),
-                                       make_float2(PBr23.x, PBi23.x), make_float2(PBr23.y, PBi23.y)};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            P[q].x = pn_row16_sum(P[q].x);
-                            P[q].y = pn_row16_sum(P[q].y);
-                        }
-                        if (c16 == 0) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) sh.yrow[16 * IB + 4 * g + q] = P[q];
-                        }
-                    }
-                    if (IA >= J0) {
-                        float2 P[4] = {make_float2(PAr01.x, PAi01.x), make_float2(PAr01.y, PAi01.y),
-                                       make_float2(PAr23.x, PAi23.x), make_float2(PAr23.y, PAi23.y)};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            P[q].x = pn_row16_sum(P[q].x);
-                            P[q].y = pn_row16_sum(P[q].y);
-                        }
-                        if (c16 == 0) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) sh.yrow[16 * IA + 4 * g + q] = P[q];
-                        }
-                    }
-                }
-            }
-            mark(2);
-            // panel dots W^H v, V^H v: over x + the unit row's term conj(X[u][jj]) hu
-            {
-                float2 dacc[(32 + 4 * NW - 1) / (4 * NW)], xu[(32 + 4 * NW - 1) / (4 * NW)];
-#pragma unroll
-                for (int q0 = 0, ps = 0; q0 < 32; q0 += 4 * NW, ++ps) {
-                    // the dots every step needs first (columns 0..3) go to the waves whose tile sets shrink first
-                    // (block rows {3, 12} / {7, 8} on SIMD 3), the W dots on waves 3..0, the V dots on waves 7..4
-                    const int qq = q0 + 4 * wave + g;
-                    const int q = ALLW ? ((qq & 16) | (15 - (qq & 15))) : (qq & 31);
-                    const int jj = q & 15;
-                    v2f acc = v2f{0.f, 0.f}, acc2 = v2f{0.f, 0.f};
-                    xu[ps] = make_float2(0.f, 0.f);
-                    if (!ALLW || (p >= 0 && jj < j)) {
-                        const float2(*X)[PN_PITCH] = (q < 16) ? sh.Wp : sh.Vp;
-                        xu[ps] = X[u][jj];
-#pragma unroll
-                        for (int i = 0; i < NT; i += 2) {
-                            acc = pk_cfma_conj(acc, pk2(X[16 * i + c16][jj]), pk2(sh.vbuf[16 * i + c16]));
-                            acc2 = pk_cfma_conj(acc2, pk2(X[16 * i + 16 + c16][jj]), pk2(sh.vbuf[16 * i + 16 + c16]));
-                        }
-                    }
-                    dacc[ps] = make_float2(acc.x + acc2.x, acc.y + acc2.y);
-                }
-#pragma unroll
-                for (int q0 = 0, ps = 0; q0 < 32; q0 += 4 * NW, ++ps) {
-                    const int qq = q0 + 4 * wave + g;
-                    const int q = ALLW ? ((qq & 16) | (15 - (qq & 15))) : (qq & 31);
-                    const int jj = q & 15;
-                    float2 t = make_float2(pn_row16_sum(dacc[ps].x), pn_row16_sum(dacc[ps].y));
-                    t = cmacc(t, xu[ps], hu);
-                    if (c16 == 0 && jj < j && p >= 0) {
-                        sh.g[q] = t;
-                        if (q >= 16) sh.Gp[jj][j] = t;
-                    }
-                }
-            }
-            mark(0);
-            __syncthreads();   // (beta)
-            mark(8);
-            // ================= phase II =================
-            if (tid < DL) {
-                if (64 * wave + 63 >= u) {   // (uniform) the wave still holds live rows
-                    const bool live = r >= u;
-                    // every load of the phase up front
-                    const float2 xr = sh.vbuf[r];                                  // (zero at and above the unit row)
-                    const float2 ucr = (j < 15) ? sh.Ap[r][j + 1] : sh.unext[r];   // column u of the panel-start matrix
-                    const float2 ucu = (j < 15) ? sh.Ap[u][j + 1] : sh.unext[u];
-                    float2 y = sh.yrow[r];
-                    float2 t[NW];
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) t[w] = sh.ycol[w][r];      // (slots above wmax hold stale finite values)
-                    float qx = 0.f;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) qx += sh.qpart[w];
-                    // the unit row: (M x)[u] and the panel corrections of row u, one term per lane
-                    float2 term = make_float2(0.f, 0.f);
-                    if (lane < 32) {
-                        if (p >= 0) {
-                            const int jj = lane & 15;
-                            const float2 X = (lane < 16) ? sh.Vp[u][jj] : sh.Wp[u][jj];
-                            const float2 gx = (lane < 16) ? sh.g[jj] : sh.g[16 + jj];
-                            term = cmul(X, gx);
-                        }
-                    } else if (lane < 32 + NW) {
-                        const int w = lane - 32;
-                        if (w <= min(NW - 1, NT - 1 - J0)) term = sh.ycol[w][u];
-                    } else if (lane == 63) {
-                        term = sh.yrow[u];
-                    }
-                    float2 xn = make_float2(0.f, 0.f), vp = xn, wp = xn, vc = xn, wc = xn;
-                    const bool next = (p >= 0 && j < 15);
-                    if (next) {
-                        xn = sh.Lbuf[(j + 1) & 1][r];
-                        if (j > 0) {   // reflector j - 1: own-row entries and the entries at the next column's row
-                            vp = sh.Vp[r][j - 1];
-                            wp = sh.Wp[r][j - 1];
-                            vc = sh.Vp[u][j - 1];
-                            wc = sh.Wp[u][j - 1];
-                        }
-                    }
-                    // -- y_x, then y = y_x + hu M[:, u] - V g1 - W g2, and Re sum conj(W_k^H v)(V_k^H v) on the way
-                    float gg = 0.f;
-                    {
-                        const int J = r >> 4;
-                        const int wmax = min(NW - 1, NT - 1 - J);
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) {
-                            if (w <= wmax) {
-                                y.x += t[w].x;
-                                y.y += t[w].y;
-                            }
-                        }
-                        const v2f yb = pk_cfma(pk2(y), pk2(hu), pk2(ucr));
-                        v2f acc = v2f{0.f, 0.f}, acc2 = v2f{0.f, 0.f};
-                        if (p >= 0) {
-                            for (int j0 = 0; j0 < j; j0 += 4) {
-                                float2 vq[4], wq[4], g1[4], g2[4];   // (columns >= j of the panel and of g are zero)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    vq[q] = sh.Vp[r][j0 + q];
-                                    wq[q] = sh.Wp[r][j0 + q];
-                                    g1[q] = sh.g[j0 + q];
-                                    g2[q] = sh.g[16 + j0 + q];
-                                }
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    acc = pk_cfma(acc, pk2(vq[q]), pk2(g1[q]));
-                                    acc2 = pk_cfma(acc2, pk2(wq[q]), pk2(g2[q]));
-                                    gg = fmaf(g1[q].x, sabs * g2[q].x, fmaf(g1[q].y, sabs * g2[q].y, gg));
-                                }
-                            }
-                        }
-                        y = make_float2(yb.x - (acc.x + acc2.x), yb.y - (acc.y + acc2.y));
-                        if (!live) y = make_float2(0.f, 0.f);
-                        const v2f ty = pk_cfma(v2f{0.f, 0.f}, pk2(tau), pk2(y));
-                        y = make_float2(ty.x, ty.y);   // p = tau y
-                    }
-                    // -- unit row: lanes 0..31 hold the correction terms, lanes 32.. the pieces of (M x)[u]
-                    float2 yxu, cu;
-                    {
-                        const float sx = pn_row16_sum(term.x), sy = pn_row16_sum(term.y);
-                        cu = make_float2(pn_readlane(sx, 0) + pn_readlane(sx, 16), pn_readlane(sy, 0) + pn_readlane(sy, 16));
-                        yxu = make_float2(pn_readlane(sx, 32) + pn_readlane(sx, 48), pn_readlane(sy, 32) + pn_readlane(sy, 48));
-                    }
-                    // |tau| (v^H M v - 2 Re sum conj(g1) g2)   (real: M Hermitian), every product formed in its scaled form
-                    const float q = qx + 2.0f * (hu.x * (sabs * yxu.x) + hu.y * (sabs * yxu.y)) +
-                                    ((hu.x * hu.x + hu.y * hu.y) * sabs) * ucu.x - 2.0f * gg;
-                    const float alv = -0.5f * sabs * q;     // -(tau / 2) p^H v = -|tau|^2 (...) / 2: real
-                    float2 wu;
-                    {
-                        const v2f yu = pk_cfma(v2f{yxu.x - cu.x, yxu.y - cu.y}, pk2(hu), pk2(ucu));
-                        const v2f pu = pk_cfma(v2f{0.f, 0.f}, pk2(tau), yu);
-                        wu = make_float2(fmaf(alv, hu.x, pu.x), fmaf(alv, hu.y, pu.y));
-                    }
-                    const float2 vr = (r == u) ? hu : xr;
-                    float2 wr = make_float2(fmaf(alv, vr.x, y.x), fmaf(alv, vr.y, y.y));
-                    if (!live) wr = make_float2(0.f, 0.f);
-                    if (r == u) wr = wu;   // the panel holds the value every thread used for the column update below
-                    sh.Vp[r][j] = vr;
-                    sh.Wp[r][j] = wr;
-                    // -- the next column enters
-                    if (next) {
-                        v2f a = pk_cfma_conj(v2f{0.f, 0.f}, pk2(wc), pk2(vp));
-                        a = pk_cfma_conj(a, pk2(vc), pk2(wp));
-                        a = pk_cfma_conj(a, pk2(wu), pk2(vr));
-                        a = pk_cfma_conj(a, pk2(hu), pk2(wr));
-                        enter_column(make_float2(xn.x - a.x, xn.y - a.y), u);
-                    }
-                }   // (a wave without live rows has nothing to do: its panel rows, its part of v and its norm partial are
-                    //  zero since the step that retired its last row)
-                mark(3);
-            } else {
-                // look-ahead of the column after next: L_{j+2} = A[:, j+2] - sum_{k<j} V[:, k] conj(W[c2][k]) + W[:, k] conj(V[c2][k])
-                if (p >= 0 && j + 2 < 16) {
-                    const int r2 = tid - DL, c2 = 16 * p + j + 2;
-                    float2 x = sh.Ap[r2][j + 2];
-                    if (r2 >= c2) {
-                        v2f acc = v2f{0.f, 0.f}, acc2 = v2f{0.f, 0.f};
-                        for (int j0 = 0; j0 < j; j0 += 4) {
-                            float2 vq[4], wq[4], vc[4], wc[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const bool on = j0 + q < j;   // (column j is being written by the row waves right now)
-                                vq[q] = on ? sh.Vp[r2][j0 + q] : make_float2(0.f, 0.f);
-                                wq[q] = on ? sh.Wp[r2][j0 + q] : make_float2(0.f, 0.f);
-                                vc[q] = sh.Vp[c2][j0 + q];
-                                wc[q] = sh.Wp[c2][j0 + q];
-                            }
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                acc = pk_cfma_conj(acc, pk2(wc[q]), pk2(vq[q]));
-                                acc2 = pk_cfma_conj(acc2, pk2(vc[q]), pk2(wq[q]));
-                            }
-                        }
-                        x.x -= acc.x + acc2.x;
-                        x.y -= acc.y + acc2.y;
-                    }
-                    sh.Lbuf[j & 1][r2] = x;
-                }
-                // column j of the panel's T factor (LAPACK clarft, forward / columnwise)
-                if (p >= 0) {
-                    const float2 gam = sh.taubuf[u];
-#pragma unroll
-                    for (int ps = 0; ps < 4 / RW; ++ps) {
-                        const int m = 4 * ((wave - RW) + RW * ps) + g, k = c16;
-                        const float2 tk = sh.Tl[m][k], gk = sh.Gp[k][j];
-                        float2 acc = (k >= m && k < j) ? cmul(tk, gk) : make_float2(0.f, 0.f);
-                        acc.x = pn_row16_sum(acc.x);
-                        acc.y = pn_row16_sum(acc.y);
-                        const float2 t = cmul(gam, acc);
-                        if (c16 == 0) sh.Tl[m][j] = (m == j) ? gam : (m < j ? make_float2(-t.x, -t.y) : make_float2(0.f, 0.f));
-                    }
-                }
-                mark(4);
-            }
-            __syncthreads();   // (alpha)
-            mark(9);
-        }
-        __syncthreads();
-        // the panel's reflectors (rows u = 16 p + 1 + jj of the image) leave in one go
-        if (tid < DL) {
-            for (int jj = (p < 0) ? 15 : 0; jj < 16; ++jj) {
-                const int uu = 16 * p + 1 + jj;
-                if (uu < DL) Mg[(int64_t)(R0 + uu) * D + R0 + tid] = sh.Vp[tid][jj];
-            }
-        }
-        if constexpr (!HEAD) {
-            if (zfill) {
-                for (int i = tid; i < 16 * R0; i += THREADS) {
-                    const int uu = 16 * p + 1 + i / R0;
-                    if (uu < DL) Mg[(int64_t)(R0 + uu) * D + i % R0] = make_float2(0.f, 0.f);
-                }
-            }
-        }
-        if (Tfac != nullptr && wave == NW - 1 && lane < 16) {
-            float2 *dst = Tfac + (bm * 17 + (P0 + p + 1)) * 256 + lane * 16;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float2 t = sh.Tl[lane][i];
-                if (p < 0) t = (lane == 15 && i == 15) ? sh.taubuf[0] : make_float2(0.f, 0.f);
-                if (16 * p + 1 + i >= DL) t = make_float2(0.f, 0.f);
-                dst[i] = t;
-            }
-        }
-        if (p == NT - 1) break;
-        // ---- trailing update on the matrix cores (as tridiag_panel_kernel): T -= V_I W_J^H + W_I V_J^H, 3M form
-        c16 = c16_0;
-        g = g_0;
-        asm volatile("" : "+v"(c16), "+v"(g));
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int P1 = p + 1;
-            const int I = half ? IA : IB;
-            asm volatile("" ::: "memory");
-            if (I < P1) continue;   // (uniform)
-            float aVr[4], aVi[4], nVs[4], aWr[4], aWi[4], nWs[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float2 v = sh.Vp[16 * I + c16][4 * g + s], w = sh.Wp[16 * I + c16][4 * g + s];
-                aVr[s] = v.x; aVi[s] = v.y; nVs[s] = v.x + v.y;
-                aWr[s] = w.x; aWi[s] = w.y; nWs[s] = w.x + w.y;
-            }
-#pragma unroll
-            for (int J = 0; J < NT; ++J) {
-                if (J >= P1 && J <= I) {   // (uniform)
-                    float2 bV[4], bW[4];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        bV[s] = sh.Vp[16 * J + c16][4 * g + s];
-                        bW[s] = sh.Wp[16 * J + c16][4 * g + s];
-                    }
-                    f32x4 re = half ? tr[NT - J] : tr[J], im = half ? ti[NT - J] : ti[J];
-                    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aVr[s], bW[s].x, s1, 0, 0, 0);
-                        s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aVi[s], bW[s].y, s2, 0, 0, 0);
-                        s3 = __builtin_amdgcn_mfma_f32_16x16x4f32(nVs[s], bW[s].x - bW[s].y, s3, 0, 0, 0);
-                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aWr[s], bV[s].x, s1, 0, 0, 0);
-                        s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aWi[s], bV[s].y, s2, 0, 0, 0);
-                        s3 = __builtin_amdgcn_mfma_f32_16x16x4f32(nWs[s], bV[s].x - bV[s].y, s3, 0, 0, 0);
-                    }
-                    const float usc = (J == I) ? 0.5f : 1.0f;
-                    re = re - (s1 + s2) * usc;
-                    im = im + ((s1 - s2) - s3) * usc;
-                    if (half) {
-                        tr[NT - J] = re;
-                        ti[NT - J] = im;
-                    } else {
-                        tr[J] = re;
-                        ti[J] = im;
-                    }
-                    if (J == P1) {
-                        const float cs = (J == I) ? 2.0f : 1.0f;
-                        float2 *dst = &sh.Ap[16 * I + 4 * g][c16];
-                        dst[0] = make_float2(re.x * cs, im.x * cs);
-                        dst[PN_PITCH] = make_float2(re.y * cs, im.y * cs);
-                        dst[2 * PN_PITCH] = make_float2(re.z * cs, im.z * cs);
-                        dst[3 * PN_PITCH] = make_float2(re.w * cs, im.w * cs);
-                    }
-                    if (J == P1 + 1 && c16 == 0) {   // (uniform + lane) column 16 (p + 2): the next panel's last unit column
-                        const float cs = (J == I) ? 2.0f : 1.0f;
-                        float2 *dst = &sh.unext[16 * I + 4 * g];
-                        dst[0] = make_float2(re.x * cs, im.x * cs);
-                        dst[1] = make_float2(re.y * cs, im.y * cs);
-                        dst[2] = make_float2(re.z * cs, im.z * cs);
-                        dst[3] = make_float2(re.w * cs, im.w * cs);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        mark(7);
-        if (p == pstop - 1) {
-#pragma unroll
-            for (int s = 0; s < NT + 1; ++s) {
-                PN_SLOT_IJ(s, I, J)
-                if (J >= pstop) {
-                    const f32x4 re = tr[s], im = ti[s];
-                    tail[pn_tail_at(I - pstop, J - pstop, 0, lane)] = make_float2(re.x, im.x);
-                    tail[pn_tail_at(I - pstop, J - pstop, 1, lane)] = make_float2(re.y, im.y);
-                    tail[pn_tail_at(I - pstop, J - pstop, 2, lane)] = make_float2(re.z, im.z);
-                    tail[pn_tail_at(I - pstop, J - pstop, 3, lane)] = make_float2(re.w, im.w);
-                }
-            }
-            break;
-        }
-        __syncthreads();
-    }
-    if constexpr (TIMING) {
-        if (lane == 0)
-            for (int i = 0; i < 14; ++i) atomicAdd(&tdbg[14 * wave + i], tacc[i]);
-    }
-    __syncthreads();
-    const int hi = (pstop < NT) ? 16 * pstop : DL;
-    for (int i = tid + (HEAD ? 0 : 1); i <= hi; i += THREADS) {
-        dcol[R0 + i] = sh.dbuf[i];
-        ecol[R0 + i] = (i < DL) ? sh.ebuf[i] : 0.f;
-        if (i < DL) Mg[(int64_t)D * D + R0 + i] = sh.taubuf[i];
-    }
-}
-
 bool tridiag_panel_supported(int D) { return D == PN_D; }
 int64_t tridiag_panel_tail_elems() { return PN_TAIL_TILES * 256; }
 
@@ -1445,34 +795,13 @@ static int pn_split() {
     return v;
 }
 
-// ADMMNET_PN_V=2 selects the two-barrier reflector step (tridiag_panel2_kernel) for A/B runs.  Measured on MI355X
-// (gpurun_out/r03_ab, 4096 matrices per launch): 9.14 / 1.87 / 0.82 ms per stage against 9.05 / 1.82 / 0.82 ms for the
-// four-barrier step, and an end-to-end accuracy ratio of 1.8 against 1.0 (test_deep_accuracy_is_statistically_the_references)
-// -- so the default stays the four-barrier step.
-static int pn_version() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("ADMMNET_PN_V");
-        v = (e && !strcmp(e, "2")) ? 2 : 1;
-    }
-    return v;
-}
-
 template <int NT, bool HEAD, bool TIMING>
 static int pn_launch_stage(int64_t nb, const Ws &ws, int pstop, unsigned long long *tdbg, hipStream_t st) {
-    if (pn_version() == 1) {
-        const size_t lds = sizeof(PnShared<NT>);
-        ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_panel_kernel<NT, HEAD, TIMING>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((tridiag_panel_kernel<NT, HEAD, TIMING>), dim3((unsigned)nb), dim3(32 * NT), lds, st, ws.Mbuf,
-                           ws.dT, ws.eT, ws.Tfac, ws.Tail, pstop, use_wy_back(PN_D) ? 0 : 1, tdbg);
-    } else {
-        const size_t lds = sizeof(PnShared2<NT>);
-        ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_panel2_kernel<NT, HEAD, TIMING>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((tridiag_panel2_kernel<NT, HEAD, TIMING>), dim3((unsigned)nb), dim3(32 * NT), lds, st, ws.Mbuf,
-                           ws.dT, ws.eT, ws.Tfac, ws.Tail, pstop, use_wy_back(PN_D) ? 0 : 1, tdbg);
-    }
+    const size_t lds = sizeof(PnShared<NT>);
+    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_panel_kernel<NT, HEAD, TIMING>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((tridiag_panel_kernel<NT, HEAD, TIMING>), dim3((unsigned)nb), dim3(32 * NT), lds, st, ws.Mbuf,
+                       ws.dT, ws.eT, ws.Tfac, ws.Tail, pstop, use_wy_back(PN_D) ? 0 : 1, tdbg);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }
@@ -1495,21 +824,17 @@ int launch_tridiag_panel(int D, int64_t nb, const Ws &ws, hipStream_t st) {
         ADMM_HIP(hipMemcpyAsync(hb, ptime, sizeof(hb), hipMemcpyDeviceToHost, st));
         ADMM_HIP(hipStreamSynchronize(st));
         ADMM_HIP(hipFree(ptime));
-        static const char *nm1[14] = {"w | column+norm", "reflector+dots", "matvec tiles", "row flush", "dot fix-up", "E: dot | look-ahead+T", "E: assemble y", "panel end + mfma",
-                                      "wait B2", "wait B3", "wait B4", "wait B5", "E: corrections", ""};
-        static const int order1[13] = {0, 8, 1, 9, 2, 3, 4, 10, 6, 12, 5, 11, 7};
-        static const char *nm2[14] = {"I: dots (+ scalars)", "I: matvec tiles", "I: x'Mx + row flush", "II: row waves", "II: look-ahead+T", "", "", "panel end + mfma",
-                                      "wait beta", "wait alpha", "", "", "", ""};
-        static const int order2[7] = {1, 2, 0, 8, 3, 4, 9};
-        const bool v2 = pn_version() == 2;
-        fprintf(stderr, "[tridiag_panel timing] v%d nb=%lld  mean kilocycles per matrix and wave\n", v2 ? 2 : 1, (long long)nb);
+        static const char *nm[14] = {"w | column+norm", "reflector+dots", "matvec tiles", "row flush", "dot fix-up", "E: dot | look-ahead+T", "E: assemble y", "panel end + mfma",
+                                     "wait B2", "wait B3", "wait B4", "wait B5", "E: corrections", ""};
+        static const int order[13] = {0, 8, 1, 9, 2, 3, 4, 10, 6, 12, 5, 11, 7};
+        fprintf(stderr, "[tridiag_panel timing] nb=%lld  mean kilocycles per matrix and wave\n", (long long)nb);
         for (int stg = 0; stg < 3; ++stg) {
             const int nw = stg == 0 ? 8 : (stg == 1 ? 4 : 2);
             if ((stg == 1 && !split) || (stg == 2 && !split3)) continue;
             fprintf(stderr, " stage %d\n", stg + 1);
-            for (int ii = 0; ii < (v2 ? 8 : 13); ++ii) {
-                const int i = v2 ? (ii < 7 ? order2[ii] : 7) : order1[ii];
-                fprintf(stderr, "   %-22s", v2 ? nm2[i] : nm1[i]);
+            for (int ii = 0; ii < 13; ++ii) {
+                const int i = order[ii];
+                fprintf(stderr, "   %-22s", nm[i]);
                 for (int w = 0; w < nw; ++w) fprintf(stderr, " %8.1f", (double)hb[112 * stg + 14 * w + i] / (double)nb / 1e3);
                 fprintf(stderr, "\n");
             }
