@@ -134,12 +134,14 @@ static void carve_chunk(Carver &c, int D, int64_t chunk, Ws *ws) {
     ws->logn = c.take<int>(chunk * 2);
     ws->Tfac = nullptr;
     ws->Tail = nullptr;
+    ws->Wmap = nullptr;
     if (use_dc()) {
         ws->Wdc = c.take<float>(chunk * 3 * n * n);
         ws->VT = c.take<float>(chunk * n * 2 * D);
         if (tridiag_panel_supported(D)) {
             ws->Tfac = c.take<float2>(chunk * 17 * 256);
             ws->Tail = c.take<float2>(chunk * tridiag_panel_tail_elems());
+            ws->Wmap = c.take<int2>(chunk * n);
         }
         ws->log = nullptr;
     } else {
@@ -218,9 +220,11 @@ static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream
     if (ws.Wdc) {   // divide & conquer + V = Q W on the matrix cores
         // the fused consumer (backrebuild.hip) and the large back-transform read the transposed image WT themselves
         const bool big = vgemm_big_supported(D);
-        if ((rc = launch_dc(D + 1, nb, ws, status, st, with_v && !big))) return rc;
+        // (the block-reflector back-transform reads the eigenvectors through the column map of the top-level merge)
+        const bool wy = big && use_wy_back(D) && with_v && ws.Wmap;
+        if ((rc = launch_dc(D + 1, nb, ws, status, st, with_v && !big, wy))) return rc;
         if (!with_v) return ADMMNET_OK;
-        if (big && use_wy_back(D)) return launch_wy_apply(D, nb, ws, st);   // block reflectors applied to W: no explicit Q
+        if (wy) return launch_wy_apply(D, nb, ws, st);   // block reflectors applied to W: no explicit Q
         return big ? launch_vgemm_big(D, nb, ws, st) : launch_vgemm(D, nb, ws, st);
     }
     if ((rc = launch_tql(D + 1, nb, ws, status, st))) return rc;

@@ -95,6 +95,8 @@ struct Ws {
     float *dT, *eT;           // [chunk][n] tridiagonal (diagonal, off-diagonal)
     float *w, *w0;            // [chunk][n] eigenvalues, first row of W
     float *Wdc;               // [chunk][3][n][n] divide & conquer: two WT ping-pong buffers + U (null: QL path)
+    int2 *Wmap;               // [chunk][n] D = 256 path: where eigenvector j of T lives after the top-level merge (float offset
+                              // into the matrix' Wdc block, valid rows lo | hi << 16) -- deflated columns are not copied there
     float *VT;                // [chunk][n][2D] eigenvectors for the rebuild (= QV on the QL path)
     float2 *Tfac;             // [chunk][17][16][16] T factors of the panel block reflectors (D = 256 path, else null)
     float2 *Tail;             // [chunk][36][4][64] trailing 128 x 128 tile set between the stages of tridiag_panel
@@ -134,7 +136,8 @@ int launch_tql(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st)
 // rotapply.hip
 int launch_rotapply(int D, int64_t nb, const Ws &ws, hipStream_t st);
 // rebuild.hip
-int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool rowmajor = true);   // dc.hip
+int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool rowmajor = true,
+              bool colmap = false);   // dc.hip (colmap: leave the top level's deflated columns in place, write Ws::Wmap)
 int64_t dc_final_offset(int n);                                                            // dc.hip
 int launch_vgemm(int D, int64_t nb, const Ws &ws, hipStream_t st);                       // dc.hip
 bool vgemm_big_supported(int D);                                                          // vgemm_big.hip

@@ -29,6 +29,7 @@ constexpr int DC_LS = 8;          // nominal leaf size (dc_leaf_start in dc_core
 constexpr int DC_MAXLEAF = 33;    // n <= 8 * 33 + 7
 constexpr int DC_MAXLS = 2 * DC_LS;   // a single leaf (n < 16) has up to 15 rows
 constexpr int DC_RA = 4;              // deflation rotations whose operands are loaded ahead (one L2 round trip per batch)
+constexpr int DC_KB = 8;              // K-steps (of two eigenvector entries each) whose operands are loaded ahead in the merge products
 constexpr int DC_FULL = 1 << 30;      // flag on a source-column index: a deflation rotation has filled all its rows
 
 // leaf scratch: Z of every leaf as [maxrows][maxrows | 1] (odd pitch: the team's row-per-lane accesses spread
@@ -49,6 +50,273 @@ struct DcShared {
     int kc[DC_MAXLEAF][2];   // per merge: non-deflated source columns with rows in the first / second block
 };
 
+// LDS carve of one workgroup: the bookkeeping block, then float / int arrays of length NP each.  Built from (smem, n)
+// wherever it is needed, so that the phases compiled as functions of their own (below) take no LDS pointers as
+// arguments -- a pointer passed through a call would lose its address space.
+struct DcCarve {
+    DcShared *sh;
+    int NP;
+    float *lam, *e0, *zv, *ds, *zs, *un, *dl, *zl, *tau, *zh, *vals, *lamn;
+    int *perm, *src, *org, *rnk, *cidx;
+    DcRot *rot;
+    float *leafZ, *leafD;
+    __device__ __forceinline__ DcCarve(char *smem, int n) {
+        sh = reinterpret_cast<DcShared *>(smem);
+        NP = (n + 3) & ~3;
+        lam = reinterpret_cast<float *>(smem + ((sizeof(DcShared) + 15) & ~(size_t)15));
+        e0 = lam + NP;
+        zv = e0 + NP;
+        ds = zv + NP;
+        zs = ds + NP;
+        un = zs;            // (after the deflation scan) 1 / ||u_j|| of the merge's rank-one eigenvectors
+        dl = zs + NP;
+        zl = dl + NP;
+        tau = zl + NP;
+        zh = tau + NP;
+        vals = zh + NP;
+        lamn = vals + NP;
+        perm = reinterpret_cast<int *>(lamn + NP);
+        src = perm + NP;
+        org = src + NP;
+        rnk = org + NP;
+        cidx = rnk + NP;                                      // source column (block-local) of merged position p
+        rot = reinterpret_cast<DcRot *>(cidx + NP);           // [NP]
+        leafZ = reinterpret_cast<float *>(rot + NP);          // [nleaf][maxrows][maxrows | 1]
+        leafD = leafZ + dc_leafz_floats(n);                   // [nleaf][2 * DC_MAXLS]
+    }
+};
+
+// The eigenvector products of one level: WTdst[rank(j)][i] = sum_kk U[kk][j] WTsrc[col(src[kk])][i] on the matrix cores,
+// waves take tiles.  A function of its own (never inlined): inside dc_kernel its 32 + 16 accumulator / operand registers met
+// the live ranges of every other phase at the 128-register budget of 4 workgroups per CU, and the allocator parked ~26
+// values in scratch around EVERY tile (reloaded before, spilled after: two L2 round trips per tile).
+template <int OCC, bool BLK>
+static __device__ __attribute__((noinline)) void dc_level_gemm(int n, int nm, int cb, const float *__restrict__ Ws,
+                                                      float *__restrict__ Wd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DcCarve cv(smem, n);
+    DcShared &sh = *cv.sh;
+    const int NP = cv.NP, tid = threadIdx.x;
+    const int *bn = sh.bnd[cb];
+    const float *dl = cv.dl, *tau = cv.tau, *un = cv.un, *zh = cv.zh;
+    const int *org = cv.org, *rnk = cv.rnk, *cidx = cv.cidx;
+    const DcRot *rot = cv.rot;
+{
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, kh = lane >> 5;
+    int gbase = 0;   // tiles of all merges of the level are dealt round-robin to the 4 waves
+    for (int mm = 0; mm < nm; ++mm) {
+        const int ma = bn[2 * mm], mc = bn[2 * mm + 2];
+        const int mnn = mc - ma, mk = sh.kk[mm], mn1 = bn[2 * mm + 1] - ma;
+        // work unit: two stacked 32 x 32 tiles (64 roots j) x 32 rows i; the B operand
+        // (source columns, the only memory stream) is shared by the pair, the A operand
+        // U[kk][j] = zh_kk / ((d_kk - d_org(j)) - tau_j) / ||u_j|| is generated in registers
+        const int tm2 = (mk + 63) >> 6, tn = (mnn + 31) >> 5;
+        const int first = (wave - gbase) & 3;
+        gbase += tm2 * tn;
+        for (int t = first; t < tm2 * tn; t += DC_THREADS / 64) {
+            const int j0 = (t / tn) * 64, i0 = (t % tn) * 32;
+            const bool two = j0 + 32 < mk;
+            const bool jv0 = (j0 + r) < mk, jv1 = (j0 + 32 + r) < mk, iv = (i0 + r) < mnn;
+            const int ja = ma + (jv0 ? j0 + r : 0), jb = ma + (jv1 ? j0 + 32 + r : 0);
+            const float dorg0 = dl[ma + org[ja]], tau0 = tau[ja], inv0 = jv0 ? un[ja] : 0.f;
+            const float dorg1 = dl[ma + org[jb]], tau1 = tau[jb], inv1 = jv1 ? un[jb] : 0.f;
+            const int io = iv ? i0 + r : 0;
+            f32x16 acc0 = {0}, acc1 = {0};
+            // row tile inside one block: only that block's source columns (list), no masks; a tile that straddles
+            // the block boundary (one per merge unless n1 is a multiple of 32) takes every column and masks
+            const bool blk1 = BLK && min(i0 + 32, mnn) <= mn1, blk2 = BLK && i0 >= mn1;
+            const int *kl = reinterpret_cast<const int *>(rot) + ma + (blk2 ? NP : 0);
+            const int kcnt = blk1 ? sh.kc[mm][0] : (blk2 ? sh.kc[mm][1] : mk);
+            const bool listed = blk1 || blk2;
+            for (int k0 = 0; k0 < kcnt; k0 += 2 * DC_KB) {   // DC_KB K-steps per batch: all loads first
+                float bv[DC_KB];
+#pragma unroll
+                for (int s16 = 0; s16 < DC_KB; ++s16) {
+                    const int ki = k0 + 2 * s16 + kh;
+                    const bool kv = ki < kcnt;
+                    const int kq = listed ? kl[kv ? ki : 0] : (kv ? ki : 0);
+                    const int cc = cidx[ma + kq], col = cc & ~DC_FULL;
+                    const float b_ = Ws[(ma + col) * n + ma + io];
+                    const bool ok = !BLK || listed || (cc & DC_FULL) || ((col < mn1) == (io < mn1));
+                    bv[s16] = (kv && iv && ok) ? b_ : 0.f;
+                }
+#pragma unroll
+                for (int s16 = 0; s16 < DC_KB; ++s16) {
+                    const int ki = k0 + 2 * s16 + kh;
+                    const bool kv = ki < kcnt;
+                    const int kc = ma + (listed ? kl[kv ? ki : 0] : (kv ? ki : 0));
+                    const float zk = kv ? zh[kc] : 0.f, dk = dl[kc];
+                    const float a0 = kv ? fdiv_fast(zk, (dk - dorg0) - tau0) * inv0 : 0.f;
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[s16], acc0, 0, 0, 0);
+                    if (two) {
+                        const float a1 = kv ? fdiv_fast(zk, (dk - dorg1) - tau1) * inv1 : 0.f;
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[s16], acc1, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int j = j0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                const int i = i0 + r;
+                if (j < mk && i < mnn) Wd[(ma + rnk[ma + j]) * n + ma + i] = acc0[q];
+                if (j + 32 < mk && i < mnn) Wd[(ma + rnk[ma + j + 32]) * n + ma + i] = acc1[q];
+            }
+        }
+    }
+}
+}
+
+// Deflation scan of one merge by ONE WAVE with the inputs in registers (levels whose teams are a wave or more).
+// Same chain, same tests and arithmetic as deflate_scan_tol (dc_core.h).  There the single walker fetches (d_j, z_j)
+// from LDS, branches four ways and stores its outputs as it goes: 600 cycles per position, 156 k cycles for the 257
+// positions of the top-level merge -- and the team form does not help on the layer matrices, where one cluster is one
+// run of rotation candidates, i.e. one walker.  Here
+//   A  lane l holds the entries l + 64 m; every lane replays the chain redundantly, so all state is wave-uniform: the
+//      operands arrive by v_readlane, the four cases are selects (no branch, no store, no wait), and what position j
+//      decided -- its case, the survivor it displaced, the rotation -- is left in lane j's registers;
+//   B  the outputs are placed by counting (ballots + prefix popcounts), all lanes storing at once.
+// A function of its own (never inlined; OCC only carries the caller's register budget over): see dc_level_gemm.
+__device__ __forceinline__ float dc_readlane(float x, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+__device__ __forceinline__ float dc_uniform(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+constexpr int DC_WSM = 5;   // 64-entry register groups: n <= 8 * DC_MAXLEAF + 7 = 271 <= 320
+// case of a position: tiny z (deflates), first non-tiny (becomes the survivor), push (the survivor before it is final: a
+// non-deflated pole; the position becomes the survivor), rotate (the survivor before it deflates into the position)
+constexpr int DW_TINY = 0, DW_FIRST = 1, DW_PUSH = 2, DW_ROT = 3;
+
+struct DwGroup {   // per lane: the record of position lane + 64 m
+    int typ, pold;         // case, survivor position before the step
+    float a, b, c;         // push: (d, z) of the displaced survivor;  rotate: (c, s, deflated pole)
+};
+
+template <int OCC>
+static __device__ __attribute__((noinline)) void deflate_scan_wave(int n, int team, int a, int nn_, float rho_, float dmax_,
+                                                                 float zmax_) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DcCarve cv(smem, n);
+    const float *ds = cv.ds + a, *zs = cv.zs + a;
+    float *dl = cv.dl + a, *zl = cv.zl + a;
+    int *src = cv.src + a;
+    DcRot *rot = cv.rot + a;
+    int *k_out = &cv.sh->kk[team], *nrot_out = &cv.sh->nrot[team];
+    const int lane = threadIdx.x & 63;
+    const int nn = __builtin_amdgcn_readfirstlane(nn_);
+    const float rho = dc_uniform(rho_), dmax = dc_uniform(dmax_), zmax = dc_uniform(zmax_);
+    const float tol = 8.0f * kEps32 * fmaxf(dmax, zmax);
+    if (rho * zmax <= tol) {   // the rank-one term is negligible: everything deflates (slot nn - 1 - j, as the serial scan)
+        for (int j = lane; j < nn; j += 64) {
+            dl[nn - 1 - j] = ds[j];
+            src[nn - 1 - j] = j;
+        }
+        if (lane == 0) {
+            *k_out = 0;
+            *nrot_out = 0;
+        }
+        return;
+    }
+    float dr[DC_WSM], zr[DC_WSM];
+#pragma unroll
+    for (int m = 0; m < DC_WSM; ++m) {
+        const int i = lane + 64 * m;
+        dr[m] = (i < nn) ? ds[i] : 0.f;
+        zr[m] = (i < nn) ? zs[i] : 0.f;
+    }
+    // ---- A: the chain
+    int pj = -1;
+    float dpj = 0.f, zpj = 0.f;
+    auto chain = [&](int m, float dreg, float zreg, DwGroup &rec) {
+        rec.typ = DW_TINY;
+        rec.pold = -1;
+        rec.a = rec.b = rec.c = 0.f;
+        const int cnt = min(64, nn - 64 * m);   // (uniform; <= 0 for absent groups)
+        for (int jj = 0; jj < cnt; ++jj) {
+            const int j = 64 * m + jj;
+            const float dj = dc_readlane(dreg, jj), zj = dc_readlane(zreg, jj);
+            const bool tiny = rho * fabsf(zj) <= tol;                 // type 1: tiny z component
+            const bool have = pj >= 0;
+            // type 2: two (nearly) equal poles -> rotate z_pj into z_j (tests as deflate_scan_tol)
+            const float q = zj * zj + zpj * zpj;
+            const float t = dj - dpj;
+            const bool close = (fabsf(t * zj * zpj) <= tol * q) && !(q < 1e-30f);
+            const float itau = rsqrt_nr(q);
+            const float tau = q * itau;
+            const float c = zj * itau, sn = -zpj * itau;
+            const float dde = dpj * c * c + dj * sn * sn;            // the pole the rotation deflates
+            const float drot = dpj * sn * sn + dj * c * c;           // the survivor's new pole
+            const int typ = tiny ? DW_TINY : (!have ? DW_FIRST : (close ? DW_ROT : DW_PUSH));
+            const bool rotd = typ == DW_ROT;
+            const bool mine = lane == jj;   // (per-lane selects: position j's record stays in its own lane)
+            rec.typ = mine ? typ : rec.typ;
+            rec.pold = mine ? pj : rec.pold;
+            rec.a = mine ? (rotd ? c : dpj) : rec.a;
+            rec.b = mine ? (rotd ? sn : zpj) : rec.b;
+            rec.c = mine ? dde : rec.c;
+            dpj = tiny ? dpj : (rotd ? drot : dj);
+            zpj = tiny ? zpj : (rotd ? tau : zj);
+            pj = tiny ? pj : j;
+        }
+    };
+    static_assert(DC_WSM == 5, "one call per register group");
+    DwGroup r0, r1, r2, r3, r4;   // (separate objects, no array: no register is indexed by a loop variable)
+    chain(0, dr[0], zr[0], r0);
+    chain(1, dr[1], zr[1], r1);
+    chain(2, dr[2], zr[2], r2);
+    chain(3, dr[3], zr[3], r3);
+    chain(4, dr[4], zr[4], r4);
+    // ---- B: emission by counting.  Before position j: ne deflation events (tiny or rotate; the serial scan fills the
+    //      deflated slots from the top, one per event), np pushes (non-deflated slots from the bottom), nr rotations.
+    int ne = 0, np = 0, nr = 0;
+    auto emit = [&](int m, float dreg, const DwGroup &rec) {
+        const int j = lane + 64 * m;
+        const bool in = j < nn;
+        const bool ev = in && (rec.typ == DW_TINY || rec.typ == DW_ROT), ps = in && rec.typ == DW_PUSH,
+                   rt = in && rec.typ == DW_ROT;
+        const unsigned long long bev = __ballot(ev), bps = __ballot(ps), brt = __ballot(rt);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int e = ne + __popcll(bev & below), pu = np + __popcll(bps & below), ro = nr + __popcll(brt & below);
+        if (ev) {
+            dl[nn - 1 - e] = rt ? rec.c : dreg;
+            src[nn - 1 - e] = rt ? rec.pold : j;
+        }
+        if (rt) {
+            DcRot r;
+            r.pa = rec.pold;
+            r.pb = j;
+            r.c = rec.a;
+            r.s = rec.b;
+            rot[ro] = r;
+        }
+        if (ps) {
+            dl[pu] = rec.a;
+            zl[pu] = rec.b;
+            src[pu] = rec.pold;
+        }
+        ne += __popcll(bev);
+        np += __popcll(bps);
+        nr += __popcll(brt);
+    };
+    emit(0, dr[0], r0);
+    emit(1, dr[1], r1);
+    emit(2, dr[2], r2);
+    emit(3, dr[3], r3);
+    emit(4, dr[4], r4);
+    if (lane == 0) {
+        int k = np;
+        if (pj >= 0) {   // the last survivor
+            dl[k] = dpj;
+            zl[k] = zpj;
+            src[k] = pj;
+            ++k;
+        }
+        *k_out = k;
+        *nrot_out = nr;
+    }
+}
+
 // BLK: the block-structured variant (no zero-fill, masked reads of source columns, merge products per block) -- worth
 // its extra registers and bookkeeping at n = 257 (needs the 128 registers of 4 waves per SIMD; the LDS admits 4
 // workgroups per CU there anyway); at n <= 129 the plain variant at 5 waves per SIMD is faster (cfg2: 7.5 vs 8.5 ms).
@@ -57,12 +325,14 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                                                         const float *__restrict__ eT, float *__restrict__ Wbuf,
                                                         float *__restrict__ wout, float *__restrict__ w0out,
                                                         int *__restrict__ logn, int32_t *__restrict__ status,
-                                                        unsigned long long *__restrict__ ptime, int rowmajor, int poison) {
+                                                        unsigned long long *__restrict__ ptime, int rowmajor, int poison,
+                                                        int2 *__restrict__ wmap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ DcShared sh;
     const int tid = threadIdx.x;
     const int64_t bm = blockIdx.x;
-    const int NP = (n + 3) & ~3;
+    const DcCarve cv(smem, n);
+    DcShared &sh = *cv.sh;
+    const int NP = cv.NP;
     // developer phase timer (ADMMNET_DC_TIMING=1): cycles of workgroup thread 0 between barriers, accumulated in
     // LDS and flushed once at the end (an atomic per mark would sit in front of the next barrier's vmcnt(0) and
     // charge its own -- contended -- latency to every phase)
@@ -80,27 +350,12 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
             t_prev = t_now;
         }
     };
-    // LDS carve (floats / ints of length NP each)
-    float *lam = reinterpret_cast<float *>(smem);
-    float *e0 = lam + NP;
-    float *zv = e0 + NP;
-    float *ds = zv + NP;
-    float *zs = ds + NP;
-    float *un = zs;            // (after the deflation scan) 1 / ||u_j|| of the merge's rank-one eigenvectors
-    float *dl = zs + NP;
-    float *zl = dl + NP;
-    float *tau = zl + NP;
-    float *zh = tau + NP;
-    float *vals = zh + NP;
-    float *lamn = vals + NP;
-    int *perm = reinterpret_cast<int *>(lamn + NP);
-    int *src = perm + NP;
-    int *org = src + NP;
-    int *rnk = org + NP;
-    int *cidx = rnk + NP;                                      // source column (block-local) of merged position p
-    DcRot *rot = reinterpret_cast<DcRot *>(cidx + NP);         // [NP]
-    float *leafZ = reinterpret_cast<float *>(rot + NP);         // [nleaf][maxrows][maxrows | 1]
-    float *leafD = leafZ + dc_leafz_floats(n);                  // [nleaf][2 * DC_MAXLS]
+    float *lam = cv.lam, *e0 = cv.e0, *zv = cv.zv, *ds = cv.ds, *zs = cv.zs, *un = cv.un, *dl = cv.dl, *zl = cv.zl,
+          *tau = cv.tau, *zh = cv.zh, *vals = cv.vals, *lamn = cv.lamn;
+    int *perm = cv.perm, *src = cv.src, *org = cv.org, *rnk = cv.rnk, *cidx = cv.cidx;
+    DcRot *rot = cv.rot;
+    float *leafZ = cv.leafZ, *leafD = cv.leafD;
+    (void)zv;
 
     float *WA = Wbuf + bm * (int64_t)3 * n * n;
     float *WB = WA + (int64_t)n * n;
@@ -132,6 +387,8 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
             w0out[bm * n + i] = 0.f;
         }
         for (int64_t i = tid; i < (int64_t)3 * n * n; i += DC_THREADS) WA[i] = 0.f;
+        if (wmap)   // the consumer follows the column map whatever happened here: point it at the zeroed first buffer
+            for (int i = tid; i < n; i += DC_THREADS) wmap[bm * n + i] = make_int2(i * n, n << 16);
         if (tid == 0) {
             logn[bm * 2 + 1] = 1;
             if (status) atomicAdd(status, 1);
@@ -267,6 +524,15 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
             const float dmx = act ? __int_as_float(sh.mx[team][0]) : 0.f, zmx = act ? __int_as_float(sh.mx[team][1]) : 0.f;
             const float tol = 8.0f * kEps32 * fmaxf(dmx, zmx);
             float *dde = reinterpret_cast<float *>(cidx);
+            // (BLK = the n = 257 route: on its layer matrices 60 - 70 % of the merges of the two top levels used to fall out
+            //  of the team scan -- one cluster is one run of rotation candidates -- so the wave scan is the primary there;
+            //  at n <= 129 the team scan rarely conflicts and is faster (cfg2: 7.7 vs 8.1 ms), the wave scan is its fallback)
+            if (BLK && ts >= 64) {   // (uniform) a wave or more per merge: the register-resident scan on the team's first wave
+                if (act && tl < 64) {
+                    deflate_scan_wave<OCC>(n, team, a, nn, rho, dmx, zmx);
+                    if (tl == 0) sh.conf[team] = 0;
+                }
+            } else {
             if (act) {
                 defl_par_flags(tl, ts, nn, rho, tol, ds + a, zs + a, org + a, rnk + a, tau + a, zh + a);
                 if (tl == 0) sh.conf[team] = 0;
@@ -278,7 +544,9 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
             __syncthreads();
             if (act) {
                 if (sh.conf[team]) {
-                    if (tl == 0) {
+                    if (ts >= 64) {   // (uniform per level)
+                        if (tl < 64) deflate_scan_wave<OCC>(n, team, a, nn, rho, dmx, zmx);
+                    } else if (tl == 0) {
                         int k = 0, nr = 0;
                         deflate_scan_tol(nn, rho, dmx, zmx, ds + a, zs + a, dl + a, zl + a, src + a, rot + a, k, nr);
                         sh.kk[team] = k;
@@ -288,6 +556,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                     defl_par_emit(tl, ts, nn, ds + a, org + a, rnk + a, tau + a, zh + a, lamn + a, vals + a, dde + a,
                                   dl + a, zl + a, src + a, rot + a, &sh.kk[team], &sh.nrot[team]);
                 }
+            }
             }
         }
         __syncthreads();
@@ -449,7 +718,26 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
         mark(6);
         // P6: new blocks.  Deflated columns are copied, the others come from the GEMM
         //     WTdst[rank(j)][i] = sum_kk U[kk][j] * WTsrc[col(src[kk])][i]   (MFMA, waves take tiles)
-        if (act) {
+        // The top-level merge with a column map (D = 256 route): its deflated columns -- 230 of 257 on the layer matrices
+        // -- stay where they are (rotated in place above), the products land in the other buffer as always, and the
+        // consumer is told where eigenvector j lives and which of its rows exist (a column no rotation filled has rows
+        // in its own block only; the others are zero by definition, not by content).
+        const bool mapped = wmap != nullptr && nblk == 2;
+        if (mapped) {
+            int2 *wm = wmap + bm * n;
+            for (int p = tl; p < nn; p += ts) {
+                const int rk = rnk[a + p];
+                if (p < k) {
+                    wm[rk] = make_int2((int)(Wd - WA) + (a + rk) * n + a, nn << 16);
+                } else {
+                    const int cc = cidx[a + p], col = cc & ~DC_FULL;
+                    const bool full = !BLK || (cc & DC_FULL);
+                    const int lo = full ? 0 : (col < n1 ? 0 : n1), hi = full ? nn : (col < n1 ? n1 : nn);
+                    wm[rk] = make_int2((int)(Ws - WA) + (a + col) * n + a, lo | (hi << 16));
+                }
+            }
+        }
+        if (act && !mapped) {
             const int cw = ts >= 32 ? 32 : ts;   // lanes per column copy
             for (int p = k + (tl / cw); p < nn; p += max(1, ts / cw)) {
                 const int cc = cidx[a + p], col = cc & ~DC_FULL;
@@ -481,70 +769,7 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
             for (int i = tid; i < w; i += DC_THREADS) lamn[pa + i] = lam[pa + i];
         }
         mark(10);
-        {
-            const int wave = tid >> 6, lane = tid & 63;
-            const int r = lane & 31, kh = lane >> 5;
-            int gbase = 0;   // tiles of all merges of the level are dealt round-robin to the 4 waves
-            for (int mm = 0; mm < nm; ++mm) {
-                const int ma = bn[2 * mm], mc = bn[2 * mm + 2];
-                const int mnn = mc - ma, mk = sh.kk[mm], mn1 = bn[2 * mm + 1] - ma;
-                // work unit: two stacked 32 x 32 tiles (64 roots j) x 32 rows i; the B operand
-                // (source columns, the only memory stream) is shared by the pair, the A operand
-                // U[kk][j] = zh_kk / ((d_kk - d_org(j)) - tau_j) / ||u_j|| is generated in registers
-                const int tm2 = (mk + 63) >> 6, tn = (mnn + 31) >> 5;
-                const int first = (wave - gbase) & 3;
-                gbase += tm2 * tn;
-                for (int t = first; t < tm2 * tn; t += DC_THREADS / 64) {
-                    const int j0 = (t / tn) * 64, i0 = (t % tn) * 32;
-                    const bool two = j0 + 32 < mk;
-                    const bool jv0 = (j0 + r) < mk, jv1 = (j0 + 32 + r) < mk, iv = (i0 + r) < mnn;
-                    const int ja = ma + (jv0 ? j0 + r : 0), jb = ma + (jv1 ? j0 + 32 + r : 0);
-                    const float dorg0 = dl[ma + org[ja]], tau0 = tau[ja], inv0 = jv0 ? un[ja] : 0.f;
-                    const float dorg1 = dl[ma + org[jb]], tau1 = tau[jb], inv1 = jv1 ? un[jb] : 0.f;
-                    const int io = iv ? i0 + r : 0;
-                    f32x16 acc0 = {0}, acc1 = {0};
-                    // row tile inside one block: only that block's source columns (list), no masks; a tile that straddles
-                    // the block boundary (one per merge unless n1 is a multiple of 32) takes every column and masks
-                    const bool blk1 = BLK && min(i0 + 32, mnn) <= mn1, blk2 = BLK && i0 >= mn1;
-                    const int *kl = reinterpret_cast<const int *>(rot) + ma + (blk2 ? NP : 0);
-                    const int kcnt = blk1 ? sh.kc[mm][0] : (blk2 ? sh.kc[mm][1] : mk);
-                    const bool listed = blk1 || blk2;
-                    for (int k0 = 0; k0 < kcnt; k0 += 32) {   // 16 K-steps per batch: all loads first
-                        float bv[16];
-#pragma unroll
-                        for (int s16 = 0; s16 < 16; ++s16) {
-                            const int ki = k0 + 2 * s16 + kh;
-                            const bool kv = ki < kcnt;
-                            const int kq = listed ? kl[kv ? ki : 0] : (kv ? ki : 0);
-                            const int cc = cidx[ma + kq], col = cc & ~DC_FULL;
-                            const float b_ = Ws[(ma + col) * n + ma + io];
-                            const bool ok = !BLK || listed || (cc & DC_FULL) || ((col < mn1) == (io < mn1));
-                            bv[s16] = (kv && iv && ok) ? b_ : 0.f;
-                        }
-#pragma unroll
-                        for (int s16 = 0; s16 < 16; ++s16) {
-                            const int ki = k0 + 2 * s16 + kh;
-                            const bool kv = ki < kcnt;
-                            const int kc = ma + (listed ? kl[kv ? ki : 0] : (kv ? ki : 0));
-                            const float zk = kv ? zh[kc] : 0.f, dk = dl[kc];
-                            const float a0 = kv ? fdiv_fast(zk, (dk - dorg0) - tau0) * inv0 : 0.f;
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[s16], acc0, 0, 0, 0);
-                            if (two) {
-                                const float a1 = kv ? fdiv_fast(zk, (dk - dorg1) - tau1) * inv1 : 0.f;
-                                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[s16], acc1, 0, 0, 0);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int j = j0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
-                        const int i = i0 + r;
-                        if (j < mk && i < mnn) Wd[(ma + rnk[ma + j]) * n + ma + i] = acc0[q];
-                        if (j + 32 < mk && i < mnn) Wd[(ma + rnk[ma + j + 32]) * n + ma + i] = acc1[q];
-                    }
-                }
-            }
-        }
+        dc_level_gemm<OCC, BLK>(n, nm, cb, Ws, Wd);
         mark(11);
         __syncthreads();
         mark(7);
@@ -569,9 +794,15 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
     // ---- outputs: eigenvalues (ascending), first row of W, status, and -- unless the consumer reads the
     //      transposed image itself (backrebuild.hip; dc_final_offset() tells it which ping-pong buffer) -- W
     //      row-major (W[i][j], j = eigenvalue) in the third region: the orientation vgemm_kernel reads coalesced
+    const bool mapped_out = wmap != nullptr && nleaf > 1;   // (Ws / Wd were swapped after the last level)
     for (int i = tid; i < n; i += DC_THREADS) {
         wout[bm * n + i] = lam[i] * unscale;
-        w0out[bm * n + i] = Ws[(int64_t)i * n];
+        if (mapped_out) {
+            const int2 e = wmap[bm * n + i];
+            w0out[bm * n + i] = ((e.y & 0xffff) == 0) ? WA[e.x] : 0.f;   // row 0 exists iff the column's rows start at 0
+        } else {
+            w0out[bm * n + i] = Ws[(int64_t)i * n];
+        }
     }
     if (rowmajor) {
         float *tile = leafZ;   // 32 x 33 floats (the leaf scratch is dead by now)
@@ -649,7 +880,8 @@ size_t dc_lds_bytes(int n) {
     const size_t nleaf = (size_t)dc_leaf_count(n);
     size_t leaf = dc_leafz_floats(n) + nleaf * 2 * DC_MAXLS;
     if (leaf < 32 * 33) leaf = 32 * 33;   // the final transpose reuses the leaf scratch as a tile
-    return sizeof(float) * 11 * NP + sizeof(int) * 5 * NP + sizeof(DcRot) * NP + sizeof(float) * leaf;
+    return ((sizeof(DcShared) + 15) & ~(size_t)15) + sizeof(float) * 11 * NP + sizeof(int) * 5 * NP + sizeof(DcRot) * NP +
+           sizeof(float) * leaf;
 }
 
 // float offset (inside one matrix' 3 n^2 block) of the ping-pong buffer that holds the final WT[j][i]: the
@@ -663,7 +895,7 @@ int64_t dc_final_offset(int n) {
     return (levels & 1) ? (int64_t)n * n : 0;
 }
 
-int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool rowmajor) {
+int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool rowmajor, bool colmap) {
     ProfScope _prof(KC_TQL, st);
     if (nb <= 0) return ADMMNET_OK;
     if (n / DC_LS > DC_MAXLEAF) {
@@ -686,7 +918,8 @@ int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, 
         ADMM_HIP(hipMemsetAsync(ptime, 0, 96 * sizeof(unsigned long long), st));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(DC_THREADS), lds, st, n, ws.dT, ws.eT, ws.Wdc, ws.w,
-                       ws.w0, ws.logn, status, ptime, rowmajor ? 1 : 0, poison ? 1 : 0);
+                       ws.w0, ws.logn, status, ptime, rowmajor ? 1 : 0, poison ? 1 : 0,
+                       (colmap && ws.Wmap && dc_leaf_count(n) > 1) ? ws.Wmap : nullptr);
     ADMM_HIP(hipGetLastError());
     if (timing) {
         unsigned long long h[96];

@@ -37,8 +37,9 @@ struct WyShared {
 
 __global__ __launch_bounds__(WY_THREADS, 3) void wy_apply_kernel(const float2 *__restrict__ Mbuf,
                                                                  const float2 *__restrict__ Tfac,
-                                                                 const float *__restrict__ Wbuf, int64_t wt_off,
-                                                                 float *__restrict__ VT, int nb) {
+                                                                 const float *__restrict__ Wbuf,
+                                                                 const int2 *__restrict__ Wmap, float *__restrict__ VT,
+                                                                 int nb) {
     __shared__ WyShared sh;
     constexpr int D = WY_D, n = D + 1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -54,15 +55,30 @@ __global__ __launch_bounds__(WY_THREADS, 3) void wy_apply_kernel(const float2 *_
     const int col = 16 * cb + c16;
     const float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
     const float2 *Tg = Tfac + bm * 17 * 256;
-    const float *WT = Wbuf + bm * (int64_t)3 * n * n + wt_off;   // WT[c][i] = W[i][c]
+    // eigenvector `col` of T through the column map of the divide & conquer's top-level merge (dc.hip): a float offset
+    // into the matrix' buffer block and the rows that exist there (the others are zero)
+    int2 wm = Wmap[bm * n + col];
+    wm.x = min(max(wm.x, 0), 3 * n * n - n);                   // (whatever the map holds, the reads stay inside the block)
+    const float *WT = Wbuf + bm * (int64_t)3 * n * n + wm.x;   // WT[i] = W[i][col]
+    const int rlo = wm.y & 0xffff, rhi = min(wm.y >> 16, n);
     float *Vb = VT + bm * ((int64_t)n * 2 * D);
 
     // X = W[1:, 16 cb .. 16 cb + 15]: tile I, register q of lane (c16, g) = X[16 I + 4 g + q][col]  (real to begin with)
     f32x4 xr[16], xi[16];
 #pragma unroll
     for (int I = 0; I < 16; ++I) {
-        const float *src = WT + (int64_t)col * n + 1 + 16 * I + 4 * g;
-        xr[I] = f32x4{src[0], src[1], src[2], src[3]};
+        const int r0 = 1 + 16 * I + 4 * g;
+        const float *src = WT + r0;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 >= rlo && r0 + 3 < rhi) {
+            v = make_float4(src[0], src[1], src[2], src[3]);
+        } else {
+            v.x = (r0 >= rlo && r0 < rhi) ? src[0] : 0.f;
+            v.y = (r0 + 1 >= rlo && r0 + 1 < rhi) ? src[1] : 0.f;
+            v.z = (r0 + 2 >= rlo && r0 + 2 < rhi) ? src[2] : 0.f;
+            v.w = (r0 + 3 >= rlo && r0 + 3 < rhi) ? src[3] : 0.f;
+        }
+        xr[I] = f32x4{v.x, v.y, v.z, v.w};
         xi[I] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
@@ -171,17 +187,23 @@ __global__ __launch_bounds__(WY_THREADS, 3) void wy_apply_kernel(const float2 *_
 constexpr int WL_BATCH = 8;
 
 __global__ __launch_bounds__(64) void wy_lastcol_kernel(const float2 *__restrict__ Mbuf, const float *__restrict__ Wbuf,
-                                                        int64_t wt_off, float *__restrict__ VT) {
+                                                        const int2 *__restrict__ Wmap, float *__restrict__ VT) {
     constexpr int D = WY_D, n = D + 1;
     const int lane = threadIdx.x;
     const int64_t bm = blockIdx.x;
     const float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
     const float2 *taus = Mg + (int64_t)D * D;
-    const float *WT = Wbuf + bm * (int64_t)3 * n * n + wt_off;   // WT[c][i] = W[i][c]
+    int2 wm = Wmap[bm * n + D];                                  // eigenvector 256 through the column map (see wy_apply_kernel)
+    wm.x = min(max(wm.x, 0), 3 * n * n - n);
+    const float *WT = Wbuf + bm * (int64_t)3 * n * n + wm.x;
+    const int rlo = wm.y & 0xffff, rhi = min(wm.y >> 16, n);
     float *Vb = VT + bm * ((int64_t)n * 2 * D);
     v2f xv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) xv[k] = v2f{WT[(int64_t)D * n + 1 + lane + 64 * k], 0.f};
+    for (int k = 0; k < 4; ++k) {
+        const int r = 1 + lane + 64 * k;
+        xv[k] = v2f{(r >= rlo && r < rhi) ? WT[r] : 0.f, 0.f};
+    }
     float2 va[WL_BATCH][4], vb[WL_BATCH][4], ta[WL_BATCH], tb[WL_BATCH];
     auto gload = [&](float2(&buf)[WL_BATCH][4], float2(&tt)[WL_BATCH], int u0) {   // reflectors u0, u0 - 1, ...
 #pragma unroll
@@ -234,15 +256,14 @@ bool use_wy_back(int D) {
 int launch_wy_apply(int D, int64_t nb, const Ws &ws, hipStream_t st) {
     ProfScope _prof(KC_ROTAPPLY, st);
     if (nb <= 0) return ADMMNET_OK;
-    if (D != WY_D || !ws.Tfac || !ws.Wdc) {
+    if (D != WY_D || !ws.Tfac || !ws.Wdc || !ws.Wmap) {
         set_error("wy_apply: D=%d unsupported (256 with the panel tridiagonalisation only)", D);
         return ADMMNET_E_ARG;
     }
-    const int n = D + 1;
     hipLaunchKernelGGL(wy_apply_kernel, dim3((unsigned)(4 * ((nb + 7) & ~(int64_t)7))), dim3(WY_THREADS), 0, st, ws.Mbuf,
-                       ws.Tfac, ws.Wdc, dc_final_offset(n), ws.VT, (int)nb);
+                       ws.Tfac, ws.Wdc, ws.Wmap, ws.VT, (int)nb);
     ADMM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(wy_lastcol_kernel, dim3((unsigned)nb), dim3(64), 0, st, ws.Mbuf, ws.Wdc, dc_final_offset(n), ws.VT);
+    hipLaunchKernelGGL(wy_lastcol_kernel, dim3((unsigned)nb), dim3(64), 0, st, ws.Mbuf, ws.Wdc, ws.Wmap, ws.VT);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }
