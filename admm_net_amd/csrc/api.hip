@@ -120,7 +120,17 @@ struct Carver {
     }
 };
 
-static void carve_chunk(Carver &c, int D, int64_t chunk, Ws *ws) {
+// 128 < D < 256 ("padded route"): the layer matrix is embedded in the D = 256 pipeline as A' = diag(A, 0) -- arrow-first
+// order puts the padding behind the last row of the D x D block.  The reflectors of A have exact zeros in the padded rows,
+// the padded columns reduce to identity reflectors (tau = 0), so T' = diag(T, 0) exactly; the padded poles deflate (z = 0)
+// with unit eigenvectors, the block reflectors leave those alone, and G' = V' f(L') V'^H = diag(G, f(0) I): the rebuild
+// stores the leading block.  Costs the D = 256 flops whatever D is, still several times faster than the per-reflector
+// sweep (tridiag_big.hip) it replaces as the default; any switch that leaves the panel / D&C / block-reflector route
+// (ADMMNET_TRIDIAG_BIG=sweep, ADMMNET_BACK=q, ADMMNET_TRIDIAG=lds, ADMMNET_EIG=ql) also leaves the padding.
+int eig_dim(int D) { return (D > 128 && D < 256 && use_wy_back(256)) ? 256 : D; }
+
+static void carve_chunk(Carver &c, int Dact, int64_t chunk, Ws *ws) {
+    const int D = eig_dim(Dact);
     const int64_t n = D + 1;
     ws->chunk = chunk;
     ws->cap = ((int64_t)kLogCapMul * n * n + 64 * n + 64 + 7) & ~(int64_t)7;   // whole 64-byte groups
@@ -208,13 +218,14 @@ static bool use_lean(int D) {
     static const bool sweep = getenv("ADMMNET_TRIDIAG_BIG") && !strcmp(getenv("ADMMNET_TRIDIAG_BIG"), "sweep");
     // D = 256 on the panel tridiagonalisation: the same idea in its "half image" form (prep.hip PM_HALF): lower-triangle
     // G / Z, image of the lower 16-block triangle -- exactly the tiles tridiag_panel_kernel loads
-    if (D > 128) return on && !lds && !sweep && use_dc() && tridiag_panel_supported(D) && use_arrow(D);
+    if (D > 128) return on && !lds && !sweep && use_dc() && tridiag_panel_supported(eig_dim(D)) && use_arrow(D);
     return on && !lds && use_arrow(D);
 }
 
-static int eig_chunk(int D, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool with_v = true,
+static int eig_chunk(int Dact, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, bool with_v = true,
                      const float2 *Zlow = nullptr, const float2 *phi = nullptr, const float *h = nullptr,
                      const float *lw = nullptr) {
+    const int D = eig_dim(Dact);   // (the image, T, W and the eigenvector image are all of this dimension)
     int rc;
     if ((rc = launch_tridiag(D, nb, ws, st, Zlow, phi, h, lw))) return rc;
     if (ws.Wdc) {   // divide & conquer + V = Q W on the matrix cores
@@ -423,7 +434,7 @@ int admmnet_layer_front(const admmnet_cfg *cfg, const float *W, int32_t k, const
         if ((rc = eig_chunk(D, nb, ws, status, st, !fused, (lean && D <= 128) ? ws.Z + b0 * n * n : nullptr, phk, hk, lw)))
             return rc;
         rc = fused ? launch_back_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, ws, st, lean)
-                   : launch_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, ws, st, lean);
+                   : launch_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, ws, st, lean, eig_dim(D));
         if (rc) return rc;
     }
     return launch_rn_sum(B, ws.rn, sum_out ? sum_out : ws.sum, st);
@@ -524,7 +535,7 @@ int admmnet_glayer_f32(const admmnet_cfg *cfg, const float *lw, const void *phi,
         float2 *Go = (float2 *)G_out + b0 * n * n;
         float *rno = rn_out ? rn_out + b0 : rn_tmp + b0, *wo = w_out ? w_out + b0 * n : nullptr;
         rc = fused ? launch_back_rebuild(D, nb, lw, ph, h + b0 * D, Go, rno, wo, ws, st)
-                   : launch_rebuild(D, nb, lw, ph, h + b0 * D, Go, rno, wo, ws, st);
+                   : launch_rebuild(D, nb, lw, ph, h + b0 * D, Go, rno, wo, ws, st, false, eig_dim(D));
         if (rc) return rc;
     }
     return ADMMNET_OK;

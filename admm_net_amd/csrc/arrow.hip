@@ -365,7 +365,7 @@ int launch_arrow_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, 
                                G, rn, ws.w, status, (unsigned long long *)nullptr, lower_only ? 1 : 0, ws.VT, ws.w0);
             ADMM_HIP(hipGetLastError());
         }
-        return launch_rebuild(D, nb, lw, phi, h, G, rn, w_out, ws, st, lower_only);
+        return launch_rebuild(D, nb, lw, phi, h, G, rn, w_out, ws, st, lower_only, D);   // (image laid out for D itself)
     }
     ProfScope _prof(KC_REBUILD, st);
     const size_t lds = ar_lds_bytes(g);

@@ -116,6 +116,7 @@ int64_t pick_chunk(const admmnet_cfg *cfg, int64_t B);
 int launch_prep(const admmnet_cfg *cfg, const float *lw, int k, const float2 *y, const float2 *b,
                 const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st,
                 bool no_matrix = false, bool lean = false);
+// (image builders: the matrix lands in an eig_dim x eig_dim image, zero outside its own D x D block)
 int launch_build_generic(int n, int64_t nb, const float2 *A, const Ws &ws, hipStream_t st);
 int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const float2 *phi, const float *h,
                        const float2 *Z, const Ws &ws, hipStream_t st);
@@ -127,6 +128,9 @@ int launch_tridiag_reg(int D, int64_t nb, const Ws &ws, hipStream_t st, const fl
                        const float *lw = nullptr);   // tridiag_reg.hip, D <= 128
 int launch_tridiag_big(int D, int64_t nb, const Ws &ws, hipStream_t st);   // tridiag_big.hip, 128 < D <= 256
 bool tridiag_panel_supported(int D);                                      // tridiag_panel.hip, D == 256
+// Dimension the eigen-pipeline works in: D itself, or 256 for 128 < D < 256 -- those geometries are embedded in the
+// D = 256 pipeline as diag(A, 0) (api.hip, "padded route"); every chunk buffer is laid out for eig_dim(D).
+int eig_dim(int D);
 int launch_tridiag_panel(int D, int64_t nb, const Ws &ws, hipStream_t st);
 int64_t tridiag_panel_tail_elems();                                       // float2 per matrix of Ws::Tail
 bool use_wy_back(int D);                                                  // wy_apply.hip: V = Q W without forming Q
@@ -153,11 +157,14 @@ int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, c
                         float *rn, float *w_out, const Ws &ws, hipStream_t st,
                         bool lower_only = false);                                        // backrebuild.hip
 bool use_dc();                                                                          // api.hip
+// image_dim: the dimension the eigenvector image ws.VT is laid out for (eig_dim(D) behind the dense pipeline, D itself
+// behind the arrowhead solver of the first layer)
 int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h,
-                   float2 *G, float *rn, float *w_out, const Ws &ws, hipStream_t st, bool lower_only = false);
+                   float2 *G, float *rn, float *w_out, const Ws &ws, hipStream_t st, bool lower_only = false,
+                   int image_dim = 0);
 int launch_vout(int n, int64_t nb, float2 *V, float *w, const Ws &ws, hipStream_t st);
-bool rebuild_big_supported(int D);                                                        // rebuild_big.hip, D == 256
-int launch_rebuild_big(int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G, float *rn,
+bool rebuild_big_supported(int D);                                                        // rebuild_big.hip, image dimension 256
+int launch_rebuild_big(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G, float *rn,
                        const Ws &ws, hipStream_t st, bool lower_only);
 // zstep.hip
 int launch_rn_sum(int64_t B, const float *rn, double *sum, hipStream_t st);

@@ -53,13 +53,24 @@ constexpr int PM_LEAN = 16;      // G / Z kept as lower triangles, A built by th
 
 // (TRI: the D = 256 triangle walk with its 16 loads in flight compiled in -- 98 VGPRs; the other instance keeps the 54
 //  registers and 8 waves per SIMD the lean D <= 128 stream wants)
+// Zero padding of an eig_dim x eig_dim image around its D x D matrix (full storage: both triangles), arrow included.
+__device__ __forceinline__ void pad_image(float2 *Mg, int D, int Dimg, int tid, int nthreads) {
+    if (Dimg <= D) return;
+    const float2 zero2 = make_float2(0.f, 0.f);
+    for (int t = tid; t < Dimg * Dimg; t += nthreads) {
+        const int i = t / Dimg, j = t - i * Dimg;
+        if (i >= D || j >= D) Mg[t] = zero2;
+    }
+    for (int j = D + tid; j < Dimg; j += nthreads) Mg[(int64_t)Dimg * Dimg + j] = zero2;
+}
+
 template <bool TRI>
 __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
     int D, int mode, const float *__restrict__ lw, const float *__restrict__ lw_prev,
     const float2 *__restrict__ y, const float2 *__restrict__ bsym, const float *__restrict__ sigma,
     float2 *__restrict__ G, float2 *__restrict__ Z, const float2 *__restrict__ phi_prev,
     const float *__restrict__ h_prev, const float *__restrict__ alpha, float2 *__restrict__ phi_out,
-    float *__restrict__ h_out, float2 *__restrict__ Mbuf) {
+    float *__restrict__ h_out, float2 *__restrict__ Mbuf, int Dimg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = D + 1;
     const int tid = threadIdx.x;
@@ -171,7 +182,9 @@ __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
     // ---- stream the matrix: finish the lazy Z update, build A (arrow-first order)
     const float corner_g = lw[S_CORNER_G], inv_rho_g = lw[S_INV_RHO_G];
     const float corner_zp = first ? 0.f : lw_prev[S_CORNER_Z];
-    float2 *Mg = Mbuf + s * ((int64_t)D * D + D + 1);
+    // (Dimg = eig_dim(D): the image is Dimg x Dimg with the matrix in its leading D x D block, the arrow and the corner
+    //  behind it as always; rows / columns D .. Dimg - 1 are zero -- the padded route of api.hip)
+    float2 *Mg = Mbuf + s * ((int64_t)Dimg * Dimg + Dimg + 1);
     if (TRI && (mode & PM_HALF)) {
         // Lower triangle only (G, Z and C are Hermitian; row D = the arrow row lies in it): half the G / Z streams,
         // about half the image.  Entries inside a diagonal 16-block also write their mirror, the arrow COLUMN of the
@@ -213,14 +226,28 @@ __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
                     Zs[idx] = zn;
                 }
                 if (i == D) {
-                    if (j == D) Mg[(int64_t)D * D + D] = make_float2(corner_g - inv_rho_g * zn.x, -inv_rho_g * zn.y);
-                    else Mg[(int64_t)D * D + j] = make_float2(phis[j].x - inv_rho_g * zn.x, phis[j].y + inv_rho_g * zn.y);   // A[j][D] = conj(A[D][j])
+                    if (j == D) Mg[(int64_t)Dimg * Dimg + Dimg] = make_float2(corner_g - inv_rho_g * zn.x, -inv_rho_g * zn.y);
+                    else Mg[(int64_t)Dimg * Dimg + j] = make_float2(phis[j].x - inv_rho_g * zn.x, phis[j].y + inv_rho_g * zn.y);   // A[j][D] = conj(A[D][j])
                 } else {
                     const float2 a = make_float2((i == j ? hs[i] : 0.f) - inv_rho_g * zn.x, -inv_rho_g * zn.y);
-                    Mg[(int64_t)i * D + j] = a;
-                    if (i != j && (i >> 4) == (j >> 4)) Mg[(int64_t)j * D + i] = make_float2(a.x, -a.y);
+                    Mg[(int64_t)i * Dimg + j] = a;
+                    if (i != j && (i >> 4) == (j >> 4)) Mg[(int64_t)j * Dimg + i] = make_float2(a.x, -a.y);
                 }
             }
+        }
+        if (Dimg > D) {   // (uniform) the padding: rows D .. Dimg - 1 of the lower 16-block triangle (whole diagonal blocks:
+                          // the block that holds row D also gets its columns >= D), the arrow entries behind D
+            const int pad = Dimg - D;
+            for (int t = tid; t < pad * Dimg; t += PR_THREADS) {
+                const int i = D + t / Dimg, j = t - (i - D) * Dimg;
+                if ((j >> 4) <= (i >> 4)) Mg[(int64_t)i * Dimg + j] = zero2;
+            }
+            const int i0 = D & ~15;                      // rows of the block that holds row D, above it
+            for (int t = tid; t < (D - i0) * 16; t += PR_THREADS) {
+                const int i = i0 + (t >> 4), j = i0 + (t & 15);
+                if (j >= D) Mg[(int64_t)i * Dimg + j] = zero2;
+            }
+            for (int j = D + tid; j < Dimg; j += PR_THREADS) Mg[(int64_t)Dimg * Dimg + j] = zero2;
         }
         return;
     }
@@ -244,18 +271,19 @@ __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
         else if (i == D) c = make_float2(corner_g, 0.f);
         else c = phis[i];
         const float2 a = make_float2(c.x - inv_rho_g * zn.x, c.y - inv_rho_g * zn.y);
-        if (i < D && j < D) Mg[(int64_t)i * D + j] = a;
-        else if (i < D) Mg[(int64_t)D * D + i] = a;
-        else Mg[(int64_t)D * D + D] = a;
+        if (i < D && j < D) Mg[(int64_t)i * Dimg + j] = a;
+        else if (i < D) Mg[(int64_t)Dimg * Dimg + i] = a;
+        else Mg[(int64_t)Dimg * Dimg + Dimg] = a;
     }
+    pad_image(Mg, D, Dimg, tid, PR_THREADS);
 }
 
 // Generic: Hermitian A[b][n][n] (lower triangle read) -> arrow-first storage, no permutation.
-__global__ void build_generic_kernel(int n, const float2 *__restrict__ A, float2 *__restrict__ Mbuf) {
+__global__ void build_generic_kernel(int n, const float2 *__restrict__ A, float2 *__restrict__ Mbuf, int Dimg) {
     const int D = n - 1;
     const int64_t b = blockIdx.x;
     const float2 *Ab = A + b * (int64_t)n * n;
-    float2 *Mg = Mbuf + b * ((int64_t)D * D + D + 1);
+    float2 *Mg = Mbuf + b * ((int64_t)Dimg * Dimg + Dimg + 1);
     for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
         const int i = idx / n, j = idx - i * n;
         float2 a;
@@ -266,20 +294,21 @@ __global__ void build_generic_kernel(int n, const float2 *__restrict__ A, float2
             a = Ab[(int64_t)j * n + i];
             a.y = -a.y;
         }
-        if (i >= 1 && j >= 1) Mg[(int64_t)(i - 1) * D + (j - 1)] = a;
-        else if (j == 0 && i >= 1) Mg[(int64_t)D * D + (i - 1)] = a;
-        else if (i == 0 && j == 0) Mg[(int64_t)D * D + D] = a;
+        if (i >= 1 && j >= 1) Mg[(int64_t)(i - 1) * Dimg + (j - 1)] = a;
+        else if (j == 0 && i >= 1) Mg[(int64_t)Dimg * Dimg + (i - 1)] = a;
+        else if (i == 0 && j == 0) Mg[(int64_t)Dimg * Dimg + Dimg] = a;
     }
+    pad_image(Mg, D, Dimg, threadIdx.x, blockDim.x);
 }
 
 // Unit-test / building-block entry: A = [[diag h, phi],[phi^H, corner]] - inv_rho Z in
 // arrow-first storage (GLayer._build_block_matrix, admm_net.py:262-290).  Z may be null.
 __global__ void build_block_kernel(int D, float corner, float inv_rho, const float2 *__restrict__ phi,
                                    const float *__restrict__ h, const float2 *__restrict__ Z,
-                                   float2 *__restrict__ Mbuf) {
+                                   float2 *__restrict__ Mbuf, int Dimg) {
     const int n = D + 1;
     const int64_t s = blockIdx.x;
-    float2 *Mg = Mbuf + s * ((int64_t)D * D + D + 1);
+    float2 *Mg = Mbuf + s * ((int64_t)Dimg * Dimg + Dimg + 1);
     for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
         const int i = idx / n, j = idx - i * n;
         if (i == D && j < D) continue;
@@ -289,17 +318,18 @@ __global__ void build_block_kernel(int D, float corner, float inv_rho, const flo
         else if (i == D) c = make_float2(corner, 0.f);
         else c = phi[s * D + i];
         const float2 a = make_float2(c.x - inv_rho * zn.x, c.y - inv_rho * zn.y);
-        if (i < D && j < D) Mg[(int64_t)i * D + j] = a;
-        else if (i < D) Mg[(int64_t)D * D + i] = a;
-        else Mg[(int64_t)D * D + D] = a;
+        if (i < D && j < D) Mg[(int64_t)i * Dimg + j] = a;
+        else if (i < D) Mg[(int64_t)Dimg * Dimg + i] = a;
+        else Mg[(int64_t)Dimg * Dimg + Dimg] = a;
     }
+    pad_image(Mg, D, Dimg, threadIdx.x, blockDim.x);
 }
 
 int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const float2 *phi, const float *h,
                        const float2 *Z, const Ws &ws, hipStream_t st) {
     if (nb <= 0) return ADMMNET_OK;
     hipLaunchKernelGGL(build_block_kernel, dim3((unsigned)nb), dim3(256), 0, st, D, corner, inv_rho, phi, h, Z,
-                       ws.Mbuf);
+                       ws.Mbuf, eig_dim(D));
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }
@@ -325,14 +355,14 @@ int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(PR_THREADS), lds, st, D, mode, lw, lwp,
                        y + b0 * D, b + b0 * D, sigma + b0, ws.G + b0 * (int64_t)n * n,
                        ws.Z + b0 * (int64_t)n * n, ws.phi[prv] + b0 * D, ws.h[prv] + b0 * D, ws.alpha + b0,
-                       ws.phi[cur] + b0 * D, ws.h[cur] + b0 * D, ws.Mbuf);
+                       ws.phi[cur] + b0 * D, ws.h[cur] + b0 * D, ws.Mbuf, eig_dim(D));
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }
 
 int launch_build_generic(int n, int64_t nb, const float2 *A, const Ws &ws, hipStream_t st) {
     if (nb <= 0) return ADMMNET_OK;
-    hipLaunchKernelGGL(build_generic_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, A, ws.Mbuf);
+    hipLaunchKernelGGL(build_generic_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, A, ws.Mbuf, eig_dim(n - 1));
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }

@@ -176,18 +176,68 @@ __global__ void vout_kernel(int n, const float *__restrict__ QV, const float *__
     }
 }
 
+// Eigenvalues (and, for the generic eigh entry, eigenvectors) of the layer matrix out of a PADDED image (api.hip: A' =
+// diag(A, 0) in the D = 256 pipeline): an eigenvector of the padding is a unit vector there, i.e. all of its weight sits in
+// the rows Da .. Dimg - 1 of the image; the others have none.  One workgroup per matrix finds them, numbers the rest in
+// ascending order (the order they come in) and writes w [na] and, if asked, V [na][na] row-major.
+__global__ void unpad_kernel(int Da, int Dimg, const float *__restrict__ VTg, const float *__restrict__ wv,
+                             const float *__restrict__ w0v, float *__restrict__ w_out, float2 *__restrict__ V) {
+    __shared__ int slot[260];
+    const int na = Da + 1, n = Dimg + 1;
+    const int64_t b = blockIdx.x;
+    const float *VT = VTg + b * ((int64_t)n * 2 * Dimg);
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        float s = 0.f;
+        for (int r = Da; r < Dimg; ++r) {
+            const float x = VT[(int64_t)c * 2 * Dimg + r], y = VT[(int64_t)c * 2 * Dimg + Dimg + r];
+            s = fmaf(x, x, fmaf(y, y, s));
+        }
+        slot[c] = s > 0.5f ? -1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int k = 0;
+        for (int c = 0; c < n; ++c)
+            if (slot[c] == 0) slot[c] = (k < na) ? k++ : -1;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += blockDim.x)
+        if (slot[c] >= 0 && w_out) w_out[b * na + slot[c]] = wv[b * n + c];
+    if (!V) return;
+    float2 *Vb = V + b * (int64_t)na * na;
+    for (int idx = threadIdx.x; idx < n * na; idx += blockDim.x) {
+        const int c = idx / na, rr = idx - c * na;   // consecutive threads -> consecutive rows (coalesced reads)
+        const int k = slot[c];
+        if (k < 0) continue;
+        float2 v;
+        if (rr == 0) v = make_float2(w0v[b * n + c], 0.f);
+        else v = make_float2(VT[(int64_t)c * 2 * Dimg + rr - 1], VT[(int64_t)c * 2 * Dimg + Dimg + rr - 1]);
+        Vb[(int64_t)rr * na + k] = v;
+    }
+}
+
 int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G,
-                   float *rn, float *w_out, const Ws &ws, hipStream_t st, bool lower_only) {
+                   float *rn, float *w_out, const Ws &ws, hipStream_t st, bool lower_only, int image_dim) {
     ProfScope _prof(KC_REBUILD, st);
     if (nb <= 0) return ADMMNET_OK;
     const int n = D + 1;
-    // D = 256: every tile resident, V^T read once (rebuild_big.hip); ADMMNET_REBUILD=tiles keeps the kernel below
+    if (image_dim <= 0) image_dim = D;
+    // image of dimension 256: every tile resident, V^T read once (rebuild_big.hip); ADMMNET_REBUILD=tiles keeps the kernel below
     static const bool tiles = getenv("ADMMNET_REBUILD") && !strcmp(getenv("ADMMNET_REBUILD"), "tiles");
-    if (!tiles && rebuild_big_supported(D)) {
-        int rc = launch_rebuild_big(nb, lw, phi, h, G, rn, ws, st, lower_only);
+    if ((!tiles || image_dim != D) && rebuild_big_supported(image_dim)) {
+        int rc = launch_rebuild_big(D, nb, lw, phi, h, G, rn, ws, st, lower_only);
         if (rc) return rc;
-        if (w_out) ADMM_HIP(hipMemcpyAsync(w_out, ws.w, sizeof(float) * nb * n, hipMemcpyDeviceToDevice, st));
+        if (w_out && image_dim == D) ADMM_HIP(hipMemcpyAsync(w_out, ws.w, sizeof(float) * nb * n, hipMemcpyDeviceToDevice, st));
+        if (w_out && image_dim != D) {
+            hipLaunchKernelGGL(unpad_kernel, dim3((unsigned)nb), dim3(256), 0, st, D, image_dim, ws.VT, ws.w, ws.w0, w_out,
+                               (float2 *)nullptr);
+            ADMM_HIP(hipGetLastError());
+        }
         return ADMMNET_OK;
+    }
+    if (image_dim != D) {
+        set_error("rebuild: no kernel for a %d-image holding D=%d", image_dim, D);
+        return ADMMNET_E_ARG;
     }
     const size_t lds = sizeof(float) * (3 * ((n + 4) & ~3) + 2 * D + 8);
     hipLaunchKernelGGL(rebuild_kernel, dim3((unsigned)nb), dim3(RB_THREADS), lds, st, D, lw, ws.VT, ws.w,
@@ -199,6 +249,11 @@ int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const 
 
 int launch_vout(int n, int64_t nb, float2 *V, float *w, const Ws &ws, hipStream_t st) {
     if (nb <= 0) return ADMMNET_OK;
+    if (eig_dim(n - 1) != n - 1) {   // padded route: drop the eigenpairs of the padding
+        hipLaunchKernelGGL(unpad_kernel, dim3((unsigned)nb), dim3(256), 0, st, n - 1, eig_dim(n - 1), ws.VT, ws.w, ws.w0, w, V);
+        ADMM_HIP(hipGetLastError());
+        return ADMMNET_OK;
+    }
     hipLaunchKernelGGL(vout_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, ws.VT, ws.w0, V);
     ADMM_HIP(hipGetLastError());
     if (w) ADMM_HIP(hipMemcpyAsync(w, ws.w, sizeof(float) * nb * n, hipMemcpyDeviceToDevice, st));

@@ -36,16 +36,20 @@ __global__ __launch_bounds__(RG_THREADS, 2) void rebuild_big_kernel(const float 
                                                                     const float *__restrict__ w0v,
                                                                     const float2 *__restrict__ phi,
                                                                     const float *__restrict__ h, float2 *__restrict__ G,
-                                                                    float *__restrict__ rn, int lower_only) {
+                                                                    float *__restrict__ rn, int lower_only, int Da) {
     __shared__ float slab[2][RG_KS][RG_PITCH];
     __shared__ float fs[264], w0f[264], z0s[264];
     __shared__ float redb[8];
+    // D, n: the image (eigenvector index c < n, rows rho < D); Da, na: the layer matrix inside it (Da < D on the padded
+    // route of api.hip: rows / columns Da .. D - 1 of G' = diag(G, f(0) I) are not stored, the padded eigenvectors have
+    // exact zeros in the stored rows and a zero first component, so they drop out of every stored entry)
     constexpr int D = RG_D, n = D + 1;
+    const int na = Da + 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, kh = lane >> 5;
     const int64_t b = blockIdx.x;
-    const LayerLayout L{D};
+    const LayerLayout L{Da};
     const float thr = lw[S_THR];
     const float *vn = lw + L.off_vn();
     for (int c = tid; c < 264; c += RG_THREADS) {
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(RG_THREADS, 2) void rebuild_big_kernel(const float 
         z0s[c] = z0;
     }
     const float *VT = VTg + b * ((int64_t)n * 2 * D);
-    float2 *Gb = G + b * (int64_t)n * n;
+    float2 *Gb = G + b * (int64_t)na * na;
 
     // tiles of this wave: t = wave + 8 s, s = 0 .. 4 (t < 36), t -> (I, J) of the lower triangle
     int tI[5], tJ[5];
@@ -139,15 +143,15 @@ __global__ __launch_bounds__(RG_THREADS, 2) void rebuild_big_kernel(const float 
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int gi = i0 + (q & 3) + 8 * (q >> 2) + 4 * kh, gj = j0 + r32;
-                if (gi >= gj) {
+                if (gi >= gj && gi < Da) {
                     const float re = aRe[s][q], im = aIm[s][q];
                     if (gi == gj) {
-                        Gb[(int64_t)gi * n + gj] = make_float2(re, 0.f);
-                        const float d = re - h[b * D + gi];
+                        Gb[(int64_t)gi * na + gj] = make_float2(re, 0.f);
+                        const float d = re - h[b * Da + gi];
                         acc2 += d * d;
                     } else {
-                        Gb[(int64_t)gi * n + gj] = make_float2(re, im);
-                        if (!lower_only) Gb[(int64_t)gj * n + gi] = make_float2(re, -im);
+                        Gb[(int64_t)gi * na + gj] = make_float2(re, im);
+                        if (!lower_only) Gb[(int64_t)gj * na + gi] = make_float2(re, -im);
                         acc2 += 2.f * (re * re + im * im);
                     }
                 }
@@ -158,12 +162,12 @@ __global__ __launch_bounds__(RG_THREADS, 2) void rebuild_big_kernel(const float 
     float *rowb = &slab[0][0][0];
     rowb[tid] = arow;
     __syncthreads();
-    if (tid < D) {
+    if (tid < Da) {
         const int o = tid;
         const float gr = rowb[o], gim = -rowb[D + o];
-        Gb[(int64_t)D * n + o] = make_float2(gr, gim);
-        if (!lower_only) Gb[(int64_t)o * n + D] = make_float2(gr, -gim);
-        const float2 p = phi[b * D + o];                  // C[D][o] = conj(phi_o)
+        Gb[(int64_t)Da * na + o] = make_float2(gr, gim);
+        if (!lower_only) Gb[(int64_t)o * na + Da] = make_float2(gr, -gim);
+        const float2 p = phi[b * Da + o];                 // C[D][o] = conj(phi_o)
         const float dr = gr - p.x, di = gim + p.y;
         acc2 += 2.f * (dr * dr + di * di);
     }
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(RG_THREADS, 2) void rebuild_big_kernel(const float 
         for (int c = lane; c < n; c += 64) g00 = fmaf(w0f[c], z0s[c], g00);
         g00 = wave_sum(g00);
         if (lane == 0) {
-            Gb[(int64_t)D * n + D] = make_float2(g00, 0.f);
+            Gb[(int64_t)Da * na + Da] = make_float2(g00, 0.f);
             const float d = g00 - lw[S_CORNER_Z];
             acc2 += d * d;
         }
@@ -187,12 +191,16 @@ __global__ __launch_bounds__(RG_THREADS, 2) void rebuild_big_kernel(const float 
     }
 }
 
-bool rebuild_big_supported(int D) { return D == RG_D; }
+bool rebuild_big_supported(int image_dim) { return image_dim == RG_D; }
 
-int launch_rebuild_big(int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G, float *rn,
+int launch_rebuild_big(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *G, float *rn,
                        const Ws &ws, hipStream_t st, bool lower_only) {
+    if (D < 1 || D > RG_D) {
+        set_error("rebuild_big: D=%d does not fit the 256 image", D);
+        return ADMMNET_E_ARG;
+    }
     hipLaunchKernelGGL(rebuild_big_kernel, dim3((unsigned)nb), dim3(RG_THREADS), 0, st, lw, ws.VT, ws.w, ws.w0, phi, h, G,
-                       rn, lower_only ? 1 : 0);
+                       rn, lower_only ? 1 : 0, D);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }

@@ -41,7 +41,8 @@ WORKLOADS = {
     "cfg2": (8, 16, 8, 4096, 32, 16),
     "cfg3": (16, 16, 16, 65536, 32, 32),
     "cfg5": (16, 16, 32, 65536, 64, 32),     # PhiEstADMMNet + alt_peak_search post-processing (main_for_net.py:99-126)
-    "ref": (10, 10, 10, 4096, 32, 16),
+    "ref": (10, 10, 10, 4096, 32, 16),        # the geometry every script of the reference uses (main_for_net.py:99, trainPhi.py:23-25)
+    "mid": (12, 16, 16, 4096, 32, 32),        # a geometry between the two tuned sizes (D = 192): the padded route of csrc/api.hip
 }
 # kernel classes of admmnet_profile_read (include/admmnet.h): "trideig" = tridiagonal eigensolver
 # (divide & conquer, or QL with ADMMNET_EIG=ql), "backtransform" = V = Q W (MFMA GEMM, or rotation replay)

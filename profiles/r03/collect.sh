@@ -27,4 +27,5 @@ if [ "$3" = "full" ]; then
 fi
 python3 profiles/r03/summarize.py $OUT $OUT/${W}_b$B
 [ "$3" = "full" ] && python3 profiles/r03/summarize.py $OUT/full $OUT/${W}_full
+find $OUT -name '*.db' -delete      # the rocpd databases (tens of MB) stay on the box: gpurun_out/ returns at most 64 MiB
 du -sh $OUT

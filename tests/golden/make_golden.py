@@ -94,6 +94,12 @@ def split_batch_case():
     print("split_batch: max|full-split| =", np.abs(full - rec["phi_split"]).max())
 
 
+def geometry_cases():
+    """A geometry between the register-resident route (D <= 128) and D = 256: 12 x 16 -> D = 192, the padded route of
+    csrc/api.hip (eig_dim).  The reference accepts any M, N (admm_net.py:726-741)."""
+    run_case("phiest_12x16_K3_perturbed", "PhiEstADMMNet", 12, 16, 3, 3, 25, True, False, False)
+
+
 def depth_cases():
     """Fixtures at the depth of the BASELINE configs (cfg2: K = 8 on 8x16; cfg3/4: K = 16 on 16x16; cfg5: K = 32)."""
     run_case("phiest_8x16_K8_perturbed", "PhiEstADMMNet", 8, 16, 8, 3, 21, True, False, False)
@@ -105,6 +111,9 @@ def depth_cases():
 if __name__ == "__main__":
     if "--depth-only" in sys.argv:
         depth_cases()
+        sys.exit(0)
+    if "--geometry-only" in sys.argv:
+        geometry_cases()
         sys.exit(0)
     run_case("phiest_3x3_K3_default", "PhiEstADMMNet", 3, 3, 3, 3, 11, False, True, False)
     run_case("phiest_3x3_K3_perturbed", "PhiEstADMMNet", 3, 3, 3, 3, 12, True, True, True)
@@ -118,3 +127,4 @@ if __name__ == "__main__":
     run_case("phiest_16x16_K3_perturbed", "PhiEstADMMNet", 16, 16, 3, 2, 20, True, False, False)
     split_batch_case()
     depth_cases()
+    geometry_cases()
