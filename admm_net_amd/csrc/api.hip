@@ -127,7 +127,14 @@ struct Carver {
 // stores the leading block.  Costs the D = 256 flops whatever D is, still several times faster than the per-reflector
 // sweep (tridiag_big.hip) it replaces as the default; any switch that leaves the panel / D&C / block-reflector route
 // (ADMMNET_TRIDIAG_BIG=sweep, ADMMNET_BACK=q, ADMMNET_TRIDIAG=lds, ADMMNET_EIG=ql) also leaves the padding.
-int eig_dim(int D) { return (D > 128 && D < 256 && use_wy_back(256)) ? 256 : D; }
+// Below kPadMin the sweep at the geometry's own size is faster than 256-sized work (measured on MI355X, K = 16, 4096
+// signals, padded vs sweep per forward: D = 160 306 vs 280 ms, D = 176 312 vs 368 ms, D = 192 319 vs 396 ms) -- ADMMNET_PAD_MIN
+// moves the switch.
+static int pad_min() {
+    static const int v = getenv("ADMMNET_PAD_MIN") ? atoi(getenv("ADMMNET_PAD_MIN")) : 176;
+    return v;
+}
+int eig_dim(int D) { return (D > 128 && D >= pad_min() && D < 256 && use_wy_back(256)) ? 256 : D; }
 
 static void carve_chunk(Carver &c, int Dact, int64_t chunk, Ws *ws) {
     const int D = eig_dim(Dact);
