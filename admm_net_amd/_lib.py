@@ -48,6 +48,8 @@ SYMBOLS = {
     "admmnet_eigh_workspace_bytes": (c_int64, [c_int32, c_int64]),
     "admmnet_eigh_c64": (c_int32, [c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                    c_void_p, c_void_p]),
+    "admmnet_vdvh_c64": (c_int32, [c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "admmnet_vhsv_f32": (c_int32, [c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "admmnet_spectrum_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     "admmnet_spectrum_f64": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p,
                                        c_int32, c_void_p, c_void_p, c_int64, c_void_p]),

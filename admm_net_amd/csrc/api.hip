@@ -585,6 +585,22 @@ int admmnet_eigh_c64(int32_t n, int64_t B, const void *A, float *w, void *V, voi
     return ADMMNET_OK;
 }
 
+int admmnet_vdvh_c64(int32_t n, int64_t B, const void *V, const float *d, void *out, void *stream) {
+    if (n < 1 || n - 1 > kMaxD || B < 1 || !V || !d || !out) {
+        set_error("vdvh: bad argument (n=%d)", n);
+        return ADMMNET_E_ARG;
+    }
+    return launch_vdvh(n, B, (const float2 *)V, d, (float2 *)out, (hipStream_t)stream);
+}
+
+int admmnet_vhsv_f32(int32_t n, int64_t B, const void *V, const void *S, float *q, void *stream) {
+    if (n < 1 || n - 1 > kMaxD || B < 1 || !V || !S || !q) {
+        set_error("vhsv: bad argument (n=%d)", n);
+        return ADMMNET_E_ARG;
+    }
+    return launch_vhsv(n, B, (const float2 *)V, (const float2 *)S, q, (hipStream_t)stream);
+}
+
 int admmnet_profile_enable(int32_t on) {
     ProfState &p = prof();
     std::lock_guard<std::mutex> lk(p.mu);

@@ -179,6 +179,10 @@ int launch_spectrum_tables(const double *taus, int nx, int xbase, const double *
 int launch_spectrum_main(const float2 *phi, int64_t B, int xbase, int ybase, const double2 *tabD, int nx,
                          const double2 *tabS, int ny, double *out, hipStream_t st);
 
+// vdvh.hip (training route)
+int launch_vdvh(int n, int64_t nb, const float2 *V, const float *d, float2 *out, hipStream_t st);
+int launch_vhsv(int n, int64_t nb, const float2 *V, const float2 *S, float *q, hipStream_t st);
+
 // synth.hip
 int launch_synth(int64_t B, int Nb, int Nd, int L, unsigned long long seed, double snr_lo, double snr_hi, double snr_e,
                  double rho, int label_iters, float2 *y, float2 *b, float *sigma, float *tau, float *f, float2 *C,

@@ -10,6 +10,7 @@
 
 CLI:  python -m admm_net_amd.harness time-net  --layers 5 --runs 1000 --out time_net_5.txt [--checkpoint best_model.pth]
       python -m admm_net_amd.harness time-admm --runs 1000 --out time.txt
+      python -m admm_net_amd.harness train-step --layers 10 --batch 256 --steps 20     (one JSON line)
 """
 from __future__ import annotations
 
@@ -138,6 +139,47 @@ def load_checkpoint(path, model, optimizer=None, scheduler=None, map_location="c
     return ckpt
 
 
+def time_train_step(layers=10, batch=256, steps=20, warmup=3, seed=0, device="cuda:0"):
+    """Wall time of one optimisation step at the reference's own training configuration (trainPhi.py:16-38: 10 x 10 grid,
+    num_layers = 10, batch_size = 256, AdamW lr 1e-3 / weight decay 1e-3, gradient clipping at 1.0, :179-190): forward in
+    train mode (the differentiable route of admm_net_amd.training: HIP eigensolver + HIP contractions), a phi-alignment
+    loss against the classical solver's phi labels (generated on the device, csrc/synth.hip), backward, clip, step.
+    The loss is a plain normalised squared error: the reference's loss.py is user code outside this path.
+    Returns a dict (seconds per step, signals per second)."""
+    from . import PhiEstADMMNet, synth
+    dev = torch.device(device)
+    torch.manual_seed(seed)
+    model = PhiEstADMMNet(num_layers=layers, M=NB, N=ND, L=3).to(dev)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-3)
+    y, b, sigma, extra = synth.make_batch_device(batch, NB, ND, seed=20260104 + seed, device=dev, labels=True)
+    label = extra["phi"].to(torch.complex64)
+    scale = label.abs().pow(2).mean()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        phi = model(y, b, sigma)
+        loss = (phi - label).abs().pow(2).mean() / scale
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        return loss
+
+    losses = []
+    for _ in range(warmup):
+        losses.append(float(step().item()))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    losses.append(float(last.item()))
+    return {"config": f"PhiEstADMMNet 10x10 K={layers}, batch {batch}, AdamW + clip 1.0 (trainPhi.py:16-38, 179-190)",
+            "seconds_per_step": round(dt, 6), "signals_per_second": round(batch / dt, 1), "steps": steps,
+            "loss_first": round(losses[0], 6), "loss_last": round(losses[-1], 6)}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -151,7 +193,15 @@ def main(argv=None):
     b.add_argument("--runs", type=int, default=1000)
     b.add_argument("--out", default=None)
     b.add_argument("--seed", type=int, default=0)
+    c = sub.add_parser("train-step")
+    c.add_argument("--layers", type=int, default=10)
+    c.add_argument("--batch", type=int, default=256)
+    c.add_argument("--steps", type=int, default=20)
     args = ap.parse_args(argv)
+    if args.cmd == "train-step":
+        import json
+        print(json.dumps(time_train_step(args.layers, args.batch, args.steps)))
+        return
     if args.cmd == "time-net":
         from . import PhiEstADMMNet
         torch.manual_seed(0)

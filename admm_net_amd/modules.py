@@ -135,10 +135,25 @@ class _FusedBase(nn.Module):
         if self._HAS_HEAD:
             self.peakSearchLayer = PeakSearchLayer(M, N, L)
         # execution knobs (not part of the reference API)
-        self.chunk = 0                 # signals per eigensolver chunk (0 = library default)
+        self._chunk = 0                # signals per eigensolver chunk (0 = library default); see the `chunk` property
         self.check_status = True       # one D2H read per forward: raise if the eigensolver failed
         self._wcache = None
         self._ws = None
+
+    @property
+    def chunk(self) -> int:
+        """Signals per eigensolver work chunk (0 = library default, 8192).  Setting it drops the cached workspace: its
+        carve depends on the chunk size."""
+        return self._chunk
+
+    @chunk.setter
+    def chunk(self, value: int):
+        value = int(value)
+        if value < 0:
+            raise ValueError("chunk must be >= 0")
+        if value != self._chunk:
+            self._chunk = value
+            self._ws = None
 
     # ---- weights -----------------------------------------------------------
     def cfg(self) -> Cfg:

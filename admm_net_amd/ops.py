@@ -52,6 +52,40 @@ def eigh(A: torch.Tensor):
     return w, V
 
 
+def vdvh(V: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+    """out = V diag(d) V^H, exactly Hermitian (admm_net.py:336-354; backward of the eigenvalue-only eigh, :303-306).
+
+    V: [B, n, n] complex64 (columns = eigenvectors), d: [B, n] float32.  Returns [B, n, n] complex64."""
+    _need_cuda(V, "V")
+    lib = _lib.load()
+    V = V.to(torch.complex64).contiguous()
+    d = d.to(device=V.device, dtype=torch.float32).contiguous()
+    B, n, _ = V.shape
+    if d.shape != (B, n):
+        raise ValueError(f"d must be [{B}, {n}], got {tuple(d.shape)}")
+    with torch.cuda.device(V.device):
+        out = torch.empty_like(V)
+        _lib.check(lib.admmnet_vdvh_c64(n, B, _ptr(V), _ptr(d), _ptr(out), _stream(V.device)), "admmnet_vdvh_c64")
+    return out
+
+
+def vhsv(V: torch.Tensor, S: torch.Tensor) -> torch.Tensor:
+    """q[b, c] = Re(v_c^H S v_c) for Hermitian S (lower triangle read): the adjoint of ``vdvh`` with respect to d.
+
+    V, S: [B, n, n] complex64.  Returns [B, n] float32."""
+    _need_cuda(V, "V")
+    lib = _lib.load()
+    V = V.to(torch.complex64).contiguous()
+    S = S.to(device=V.device, dtype=torch.complex64).contiguous()
+    B, n, _ = V.shape
+    if S.shape != V.shape:
+        raise ValueError("S must have the shape of V")
+    with torch.cuda.device(V.device):
+        q = torch.empty(B, n, dtype=torch.float32, device=V.device)
+        _lib.check(lib.admmnet_vhsv_f32(n, B, _ptr(V), _ptr(S), _ptr(q), _stream(V.device)), "admmnet_vhsv_f32")
+    return q
+
+
 def glayer(model, k: int, phi: torch.Tensor, h: torch.Tensor, Z=None):
     """GLayer.forward (admm_net.py:237-354) of layer k of ``model`` plus the Z-layer residual norm.
 

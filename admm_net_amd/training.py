@@ -6,7 +6,10 @@ takes this route instead: the layers are evaluated as differentiable tensor oper
 the Hermitian eigendecomposition -- the dominant cost of every layer (admm_net.py:303) -- runs on the
 HIP eigensolver behind ``admmnet_eigh_c64`` with the gradient the reference defines for it: the
 eigenvectors are detached (admm_net.py:306), so only the eigenvalues carry gradient,
-``dL/dA = V diag(dL/dw) V^H``.
+``dL/dA = V diag(dL/dw) V^H``.  The two n^3 contractions around it -- the rebuild ``G = V f(L) V^H`` of
+admm_net.py:336-354 (forward, and its adjoint ``Re(v_c^H S v_c)`` in the backward) and that ``V diag(gw) V^H`` -- run on
+the library's matrix-core kernels too (``admmnet_vdvh_c64`` / ``admmnet_vhsv_f32``, csrc/vdvh.hip), not on framework
+GEMMs; the remaining layer steps are O(n^2) tensor operations.
 
 Gradient flow mirrors the reference as written:
   * the corner values ``1 / (softplus(lambda)^2 + eps)`` go through ``.item()`` (admm_net.py:271, 426):
@@ -30,21 +33,60 @@ from . import ops
 EPS = 1e-8   # every layer's epsilon (admm_net.py:74, 114, 211, 360)
 
 
+class Assembler:
+    """The two contractions with a constant eigenvector matrix: ``vdvh(V, d) = V diag(d) V^H`` (exactly Hermitian)
+    and its adjoint ``vhsv(V, S)[c] = Re(v_c^H S v_c)`` for Hermitian S.  The product uses the HIP kernels; the CPU unit
+    tests hand in ``TorchAssembler`` to check the autograd wiring without a GPU."""
+
+    vdvh = staticmethod(ops.vdvh)
+    vhsv = staticmethod(ops.vhsv)
+
+
+class TorchAssembler:
+    """Stand-in for tests (tensor operations on whatever device the inputs live on)."""
+
+    @staticmethod
+    def vdvh(V, d):
+        G = torch.matmul(V * d.unsqueeze(1).to(V.dtype), V.transpose(1, 2).conj())
+        return 0.5 * (G + G.transpose(1, 2).conj())
+
+    @staticmethod
+    def vhsv(V, S):
+        return (V.conj() * torch.matmul(S, V)).sum(dim=1).real
+
+
 class _EighValuesOnly(torch.autograd.Function):
     """(w, V) = eigh(A) with V constant: backward is V diag(gw) V^H (admm_net.py:303-306)."""
 
     @staticmethod
-    def forward(ctx, A, solver):
+    def forward(ctx, A, solver, asm):
         w, V = solver(A.detach())
         ctx.save_for_backward(V)
+        ctx.asm = asm
         ctx.mark_non_differentiable(V)
         return w, V
 
     @staticmethod
     def backward(ctx, gw, _gV):
         (V,) = ctx.saved_tensors
-        gA = torch.matmul(V * gw.unsqueeze(1).to(V.dtype), V.transpose(1, 2).conj())
-        return gA, None
+        return ctx.asm.vdvh(V, gw.to(torch.float32)), None, None
+
+
+class _Rebuild(torch.autograd.Function):
+    """G = (G0 + G0^H) / 2 with G0 = V diag(d) V^H, V constant (admm_net.py:336-354); d carries the gradient
+    Re(v_c^H S v_c) with S = (g + g^H) / 2, the backward of the symmetrisation followed by that of the two products."""
+
+    @staticmethod
+    def forward(ctx, V, d, asm):
+        ctx.save_for_backward(V)
+        ctx.asm = asm
+        return asm.vdvh(V, d)
+
+    @staticmethod
+    def backward(ctx, g):
+        (V,) = ctx.saved_tensors
+        S = 0.5 * (g + g.transpose(1, 2).conj())
+        return None, ctx.asm.vhsv(V, S), None
 
 
 def _block_matrix(phi: torch.Tensor, h: torch.Tensor, corner: float) -> torch.Tensor:
@@ -75,16 +117,15 @@ def _h_layer(layer, G, Z, sigma):
     return tc * scale
 
 
-def _g_layer(layer, phi, h, Z, solver):
+def _g_layer(layer, phi, h, Z, solver, asm):
     """admm_net.py:237-354."""
     corner = (1.0 / (F.softplus(layer.lambda_param) ** 2 + EPS)).item()
     A = _block_matrix(phi, h, corner) - (1.0 / (F.softplus(layer.rho) + EPS)) * Z
     A = 0.5 * (A + A.transpose(1, 2).conj())
-    w, V = _EighValuesOnly.apply(A, solver)
+    w, V = _EighValuesOnly.apply(A, solver, asm)
     # learned eigenvalue map, every eigenvalue through the same 1 -> 16 -> 1 network (admm_net.py:310-334)
     wp = F.softplus(w - torch.sigmoid(layer.threshold)) * layer.value_net(w.abs().unsqueeze(-1)).squeeze(-1)
-    G = torch.matmul(V * wp.unsqueeze(1).to(V.dtype), V.transpose(1, 2).conj())
-    return 0.5 * (G + G.transpose(1, 2).conj())
+    return _Rebuild.apply(V, wp, asm)
 
 
 def _z_layer(layer, k, phi, h, G, Z):
@@ -118,14 +159,16 @@ def _peak_head(head, phi):
 
 
 def unrolled_forward(model, y: torch.Tensor, b: torch.Tensor, sigma: torch.Tensor,
-                     solver: Optional[Callable] = None):
+                     solver: Optional[Callable] = None, assembler=None):
     """Differentiable K-layer forward on the device of ``y`` (admm_net.py:742-764 / 791-816).
 
-    ``solver(A) -> (w, V)`` defaults to the HIP eigensolver; the CPU unit tests pass a stand-in to check
-    the autograd wiring against the reference's gradients without a GPU.
+    ``solver(A) -> (w, V)`` defaults to the HIP eigensolver and ``assembler`` to the HIP contractions; the CPU unit
+    tests pass stand-ins (``torch.linalg.eigh``, ``TorchAssembler``) to check the autograd wiring against the reference's
+    gradients without a GPU.
     Returns phi, or (tau, f, confidences, phi) when the model has a PeakSearchLayer.
     """
     solver = ops.eigh if solver is None else solver
+    asm = Assembler if assembler is None else assembler
     K, D = model.num_layers, model.M * model.N
     if y.dim() != 2 or y.shape[1] != D or b.shape != y.shape:
         raise ValueError(f"y, b must be [B, {D}] complex; got {tuple(y.shape)}, {tuple(b.shape)}")
@@ -141,7 +184,7 @@ def unrolled_forward(model, y: torch.Tensor, b: torch.Tensor, sigma: torch.Tenso
         if k == K - 1:
             break
         h = _h_layer(model.hLayers[k], G, Z, sigma)
-        G = _g_layer(model.gLayers[k], phi, h, Z, solver)
+        G = _g_layer(model.gLayers[k], phi, h, Z, solver, asm)
         Z = _z_layer(model.zLayers[k], k, phi, h, G, Z)
     if getattr(model, "_HAS_HEAD", False):
         tau, f, conf = _peak_head(model.peakSearchLayer, phi)

@@ -151,6 +151,15 @@ int admmnet_eigh_c64(int32_t n, int64_t B, const void *A, float *w, void *V,
                      void *workspace, int64_t workspace_bytes,
                      int32_t *status, void *stream);
 
+/* Training route (trainPhi.py / train.py call forward in train mode).
+ * admmnet_vdvh_c64: out = V diag(d) V^H, exactly Hermitian -- GLayer._rebuild_definite_matrix (admm_net.py:336-354: two
+ *   bmm + the symmetrisation) and the backward of the eigenvalue-only eigh, dL/dA = V diag(dL/dw) V^H (admm_net.py:303-306,
+ *   V detached).   V device complex64 [B][n][n] (columns = eigenvectors), d device float [B][n], out complex64 [B][n][n].
+ * admmnet_vhsv_f32: its adjoint, q[c] = Re(v_c^H S v_c) for a Hermitian S (lower triangle read): the gradient of out with
+ *   respect to d for an incoming S = (g + g^H) / 2.   S device complex64 [B][n][n], q device float [B][n]. */
+int admmnet_vdvh_c64(int32_t n, int64_t B, const void *V, const float *d, void *out, void *stream);
+int admmnet_vhsv_f32(int32_t n, int64_t B, const void *V, const void *S, float *q, void *stream);
+
 /* Spectrum |phi^H kron(s(f), conj d(tau))|^2 on a (tau, f) grid:
  * peak_search_func / peak_search, utils/peakSearchUtils.py:9-60, evaluated in
  * float64 like the reference.

@@ -68,7 +68,7 @@ def cpu_eigh(Amat):
 def test_autograd_wiring_matches_reference_gradients(path):
     z, m, head, t = load(path)
     m.eval()   # fixture convention: dropout off
-    out = training.unrolled_forward(m, t("y"), t("b"), t("sigma"), solver=cpu_eigh)
+    out = training.unrolled_forward(m, t("y"), t("b"), t("sigma"), solver=cpu_eigh, assembler=training.TorchAssembler)
     phi = out[3] if head else out
     assert np.abs(phi.detach().numpy() - z["phi"]).max() <= 2e-5 * np.abs(z["phi"]).max()
     loss = loss_of(out, t, head)
@@ -84,7 +84,49 @@ def test_train_mode_without_gpu_fails_loudly():
         m(torch.zeros(1, 9, dtype=torch.complex64), torch.ones(1, 9, dtype=torch.complex64), torch.ones(1))
 
 
+def test_rebuild_function_has_the_gradient_of_the_two_products():
+    """``_Rebuild`` (V diag(d) V^H + symmetrisation as ONE function with a hand-written backward) against autograd
+    through the reference's own formulation -- two matmuls and the symmetrisation (admm_net.py:336-354)."""
+    torch.manual_seed(0)
+    B, n = 3, 7
+    X = torch.randn(B, n, n, dtype=torch.complex128)
+    V = torch.linalg.eigh(X + X.transpose(1, 2).conj())[1]
+    d1 = torch.randn(B, n, dtype=torch.float64, requires_grad=True)
+    d2 = d1.detach().clone().requires_grad_(True)
+    c = torch.randn(B, n, n, dtype=torch.complex128)
+    G1 = training._Rebuild.apply(V, d1, training.TorchAssembler)
+    G0 = torch.matmul(torch.matmul(V, torch.diag_embed(d2).to(V.dtype)), V.transpose(1, 2).conj())
+    G2 = 0.5 * (G0 + G0.transpose(1, 2).conj())
+    assert torch.allclose(G1, G2, atol=1e-12)
+    (c.conj() * G1).real.sum().backward()
+    (c.conj() * G2).real.sum().backward()
+    assert torch.allclose(d1.grad, d2.grad, atol=1e-11), (d1.grad - d2.grad).abs().max()
+
+
 # ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_assembly_kernels_match_their_definitions():
+    """admmnet_vdvh_c64 / admmnet_vhsv_f32 (csrc/vdvh.hip) against float64 evaluations of V diag(d) V^H and
+    Re(v_c^H S v_c), at the reference's n = 101, at a ragged small size and at n = 257; the assembled matrix is exactly
+    Hermitian."""
+    from admm_net_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1)
+    for n, B in ((101, 5), (7, 3), (257, 2), (33, 4)):
+        X = torch.randn(B, n, n, dtype=torch.complex128, generator=g)
+        V = torch.linalg.eigh(X + X.transpose(1, 2).conj())[1]
+        d = torch.randn(B, n, dtype=torch.float64, generator=g)
+        Y = torch.randn(B, n, n, dtype=torch.complex128, generator=g)
+        S = Y + Y.transpose(1, 2).conj()
+        want = torch.matmul(V * d.unsqueeze(1), V.transpose(1, 2).conj())
+        got = ops.vdvh(V.to(dev, torch.complex64), d.to(dev, torch.float32)).cpu().to(torch.complex128)
+        assert (got - want).abs().max() <= 2e-6 * want.abs().max() * (n ** 0.5)
+        assert torch.equal(got, got.transpose(1, 2).conj())
+        wq = (V.conj() * torch.matmul(S, V)).sum(dim=1).real
+        gq = ops.vhsv(V.to(dev, torch.complex64), S.to(dev, torch.complex64)).cpu().to(torch.float64)
+        assert (gq - wq).abs().max() <= 2e-6 * wq.abs().max() * (n ** 0.5)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
 def test_hip_training_gradients_match_reference(path):
