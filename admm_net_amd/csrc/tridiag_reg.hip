@@ -377,8 +377,8 @@ struct TrPhases {
 // the prep kernel would have to write first (A is Hermitian: 36 of the 64 register blocks are loaded, the
 // rest are their conjugate transposes, fetched from the owning threads through LDS).  Per signal and layer
 // this removes a 131 KB write and a 131 KB read of the image and halves the G / Z streams of the prep kernel.
-template <int NA, bool LEAN>
-__global__ __launch_bounds__(TR_THREADS, 2) void tridiag_reg_kernel(int D, float2 *__restrict__ Mbuf,
+template <int NA, bool LEAN, int OCC = 2>
+__global__ __launch_bounds__(TR_THREADS, OCC) void tridiag_reg_kernel(int D, float2 *__restrict__ Mbuf,
                                                                     float *__restrict__ QV,
                                                                     float *__restrict__ dT,
                                                                     float *__restrict__ eT,
@@ -526,6 +526,22 @@ static int launch_tr(int D, int64_t nb, const Ws &ws, hipStream_t st, const floa
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pad));
         ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_reg_kernel<NA, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+    }
+    // NA = 7 (97 <= D <= 112, the reference's 10 x 10 geometry): compiled for THREE workgroups per CU (168 registers, a few
+    // values in scratch) -- the kernel is a latency chain per reflector and a third matrix per CU hides more of it than the
+    // spills cost; ADMMNET_TR_OCC=2 keeps the two-workgroup build for A/B runs.
+    static const int occ3 = !(getenv("ADMMNET_TR_OCC") && atoi(getenv("ADMMNET_TR_OCC")) == 2);
+    if constexpr (NA == 7) {
+        if (occ3 && pad == 0) {
+            if (Zlow)
+                hipLaunchKernelGGL((tridiag_reg_kernel<NA, true, 3>), dim3((unsigned)nb), dim3(TR_THREADS), 0, st, D, ws.Mbuf,
+                                   ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw);
+            else
+                hipLaunchKernelGGL((tridiag_reg_kernel<NA, false, 3>), dim3((unsigned)nb), dim3(TR_THREADS), 0, st, D, ws.Mbuf,
+                                   ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw);
+            ADMM_HIP(hipGetLastError());
+            return ADMMNET_OK;
+        }
     }
     if (Zlow)
         hipLaunchKernelGGL((tridiag_reg_kernel<NA, true>), dim3((unsigned)nb), dim3(TR_THREADS), pad, st, D, ws.Mbuf,
