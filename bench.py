@@ -98,13 +98,13 @@ def host_threads():
 
 
 def spawn_ranks(n):
-    import socket
+    """A plain `python bench.py --gpus N`: start the N ranks as CHILD processes (torch.distributed.run, one per GPU) before
+    anything here touches the GPU, relay their output and return their status.  `--standalone` lets the launcher pick its
+    own rendezvous port (no bind-close-reuse race between several launches on one host); 127.0.0.1 because the container
+    hostname may not resolve."""
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
     log("launching %d ranks: %s" % (n, " ".join(cmd)))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
