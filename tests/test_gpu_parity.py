@@ -329,10 +329,12 @@ def test_degenerate_inputs_match_oracle(dev, geom):
 
 
 @pytest.mark.parametrize("K", [2, 3])
-@pytest.mark.parametrize("geom", [(3, 3), (16, 16)])
+@pytest.mark.parametrize("geom", [(3, 3), (16, 16), (12, 16), (10, 16)])
 def test_fails_loudly_on_nonfinite_input(dev, K, geom):
     """torch.linalg.eigh raises on non-finite input (admm_net.py:303); so must every eigen-path: K = 2 has the arrowhead
-    solver as its ONLY G-layer (arrow.hip), K = 3 adds a dense layer; 16x16 takes the D > 128 kernels."""
+    solver as its ONLY G-layer (arrow.hip), K = 3 adds a dense layer; 16x16 takes the D = 256 kernels, 12x16 the same
+    pipeline on the padded matrix (the back-transform follows the D&C's column map, which the early exit must still
+    write), 10x16 the per-reflector sweep at its own size."""
     Nb, Nd = geom
     m = A.PhiEstADMMNet(M=Nb, N=Nd, num_layers=K).eval()
     y, b, s, _ = synth.make_batch(2, Nb, Nd, seed=1)
