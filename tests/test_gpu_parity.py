@@ -417,6 +417,46 @@ def test_deep_accuracy_is_statistically_the_references(dev):
     assert float(np.exp(np.mean(np.log(ratios)))) < 1.6, ratios
 
 
+@pytest.mark.timeout(900)
+def test_cfg3_full_batch_properties(dev):
+    """BASELINE cfg 3 at ITS size (K = 16, D = 256, B = 65 536: eight eigen-chunks of 8192, ~90 GB of state, 5 s per
+    forward on the MI355X) -- far beyond the oracle, so properties, as for cfg 2:
+    (i) the layer-at-a-time forward (what bench.py times) equals the one-call forward bit for bit;
+    (ii) six signals spread over the chunks, evaluated by the float64 oracle with the full-batch means of the HIP run
+         injected, agree to the fp32 tolerance -- this pins the chunked D = 256 pipeline at the bench's own geometry;
+    (iii) reversing the batch reverses the output (the only coupling is the batch mean; a reversal moves every signal
+          to a different chunk and chunk position)."""
+    Nb, Nd, K, B = 16, 16, 16, 65536
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 120e9:
+        pytest.skip("needs ~100 GB of free HBM")
+    torch.manual_seed(0)
+    m = A.PhiEstADMMNet(M=Nb, N=Nd, num_layers=K).eval()
+    ty, tb, ts, _ = synth.make_batch_device(B, Nb, Nd, seed=20260104, device=dev)
+    phi = m(ty, tb, ts)
+    assert torch.isfinite(torch.view_as_real(phi)).all()
+    eng = sharded.HipLayerEngine(m, ty, tb, ts)
+    eng.begin()
+    means = []
+    for k in range(K):
+        sc = eng.front(k)
+        if k == K - 1:
+            break
+        means.append(float(sc[0].item()) / B)
+        eng.back(k, sc[0] / sc[1])
+    phi2, _ = eng.finish()
+    assert torch.equal(phi2, phi)
+    idx = torch.tensor([0, 8191, 8192, 30000, 57344, 65535])
+    sd = {k_: v.detach() for k_, v in m.state_dict().items()}
+    o = R.forward(sd, ty[idx.to(dev)].cpu(), tb[idx.to(dev)].cpu(), ts[idx.to(dev)].cpu(), Nb, Nd, K, dtype="f64",
+                  skip_dead_tail=True, mean_norm_fn=lambda k, rn: torch.tensor(means[k], dtype=rn.dtype))
+    assert rel(phi[idx.to(dev)].cpu().numpy(), o.numpy()) < TOL_PHI
+    keep = phi[idx.to(dev)].clone()
+    del phi, phi2
+    phi_r = m(ty.flip(0), tb.flip(0), ts.flip(0))
+    assert rel(phi_r[(B - 1 - idx).to(dev)].cpu().numpy(), keep.cpu().numpy()) < 2e-5
+
+
 def test_cfg3_shape_small_batch(dev):
     """BASELINE cfg 3/4/5 geometry (D=256, n=257, K=16) on a batch the oracle finishes in seconds."""
     Nb, Nd, K, B = 16, 16, 16, 3

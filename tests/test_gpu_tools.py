@@ -171,3 +171,35 @@ def test_cfg5_post_processing_on_a_2048_atom_grid(dev):
         got = pk[i, :cnt[i]]
         assert np.array_equal(got[:, :2], want[:, :2])
         assert np.abs(got[:, 2] - want[:, 2]).max() <= 1e-9 * want[:, 2].max()
+
+
+@pytest.mark.timeout(900)
+def test_cfg5_full_batch_properties(dev):
+    """BASELINE cfg5 at ITS size: K = 32 PhiEstADMMNet on 65 536 signals of a 16 x 16 grid followed by the device
+    alt_peak_search on the 2048-atom coarse grid -- bench.py --workload cfg5's timed step.  Far beyond the oracle, so:
+    every phi finite; for signals spread over the eigen-chunks, the peak list of the device search equals the
+    oracle's literal alt_peak_search on the same phi (positions bit-exact, heights to float64 rounding); and the peak
+    lists of the whole batch are those of its reversal, reversed."""
+    Nb = Nd = 16
+    K, B = 32, 65536
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 120e9:
+        pytest.skip("needs ~100 GB of free HBM")
+    opts = {"xstep": 1.0 / 65, "ystep": 1.0 / 32, "iter": 2}
+    torch.manual_seed(0)
+    m = A.PhiEstADMMNet(M=Nb, N=Nd, num_layers=K).eval()
+    ty, tb, ts, _ = synth.make_batch_device(B, Nb, Nd, seed=20260104, device=dev)
+    phi = m(ty, tb, ts)
+    assert torch.isfinite(torch.view_as_real(phi)).all()
+    pk, cnt = ops.peak_search(phi, Nd, Nb, opts, max_peaks=256)
+    idx = [0, 8191, 8192, 40000, 65535]
+    ph = phi[idx].cpu().numpy()
+    pkh, cnh = pk[idx].cpu().numpy(), cnt[idx].cpu().numpy()
+    for i in range(len(idx)):
+        want = PO.alt_peak_search_literal({"phi": ph[i].astype(np.complex128), "xbase": Nd, "ybase": Nb}, opts)
+        assert cnh[i] == want.shape[0] and 0 < cnh[i] <= 256
+        got = pkh[i, :cnh[i]]
+        assert np.array_equal(got[:, :2], want[:, :2])
+        assert np.abs(got[:, 2] - want[:, 2]).max() <= 1e-9 * want[:, 2].max()
+    pk_r, cnt_r = ops.peak_search(phi.flip(0).contiguous(), Nd, Nb, opts, max_peaks=256)
+    assert torch.equal(cnt_r.flip(0), cnt) and torch.equal(pk_r.flip(0), pk)
