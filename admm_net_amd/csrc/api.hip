@@ -175,6 +175,45 @@ int64_t eig_chunk_bytes(int D, int64_t chunk) {
     return c.off;
 }
 
+// Two chunks in flight (ADMMNET_STREAMS=2): the per-chunk kernel sequence prep -> tridiagonalisation -> D&C -> back-transform ->
+// rebuild of consecutive chunks alternates between two internal streams and two sets of chunk buffers, so that the
+// vector-ALU-bound kernels of one chunk and the matrix-core-bound kernels of the other can share the CUs wherever their
+// registers and LDS admit both.  Only for batches of at least two chunks; the state (G, Z, phi, h, rn) is shared -- the
+// chunks touch disjoint slices of it.
+static bool two_streams() {
+    static const bool on = getenv("ADMMNET_STREAMS") && atoi(getenv("ADMMNET_STREAMS")) == 2;
+    return on;
+}
+
+struct ChunkStreams {   // per device, created on first use (non-blocking streams: they order against the caller's by events)
+    std::mutex mu;
+    hipStream_t s[2] = {nullptr, nullptr};
+    int dev = -1;
+};
+static int chunk_streams(hipStream_t out[2]) {
+    static ChunkStreams cs[16];
+    int dev = 0;
+    ADMM_HIP(hipGetDevice(&dev));
+    ChunkStreams &c = cs[dev & 15];
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.s[0] == nullptr || c.dev != dev) {
+        ADMM_HIP(hipStreamCreateWithFlags(&c.s[0], hipStreamNonBlocking));
+        ADMM_HIP(hipStreamCreateWithFlags(&c.s[1], hipStreamNonBlocking));
+        c.dev = dev;
+    }
+    out[0] = c.s[0];
+    out[1] = c.s[1];
+    return ADMMNET_OK;
+}
+
+static void carve_chunk(Carver &c, int Dact, int64_t chunk, Ws *ws);
+
+// the second set of chunk buffers (same layout as the first; state pointers copied from `ws`)
+static void carve_second_set(Carver &c, int D, const Ws &ws, Ws *ws2) {
+    *ws2 = ws;
+    carve_chunk(c, D, ws.chunk, ws2);
+}
+
 int carve_workspace(const admmnet_cfg *cfg, int64_t B, void *base, int64_t bytes, Ws *ws, bool state) {
     const int D = cfg->M * cfg->N;
     const int64_t n = D + 1;
@@ -192,6 +231,12 @@ int carve_workspace(const admmnet_cfg *cfg, int64_t B, void *base, int64_t bytes
         ws->headkv = c.take<float>((int64_t)2 * D * 128);
     }
     carve_chunk(c, D, pick_chunk(cfg, B), ws);
+    ws->set2_offset = 0;
+    if (state && two_streams() && B > ws->chunk) {   // room for a second chunk in flight
+        ws->set2_offset = c.off;
+        Ws tmp;
+        carve_second_set(c, D, *ws, &tmp);
+    }
     ws->total_bytes = c.off;
     if (base && bytes < c.off) {
         set_error("workspace too small: %lld < %lld bytes", (long long)bytes, (long long)c.off);
@@ -424,25 +469,52 @@ int admmnet_layer_front(const admmnet_cfg *cfg, const float *W, int32_t k, const
     if (k == cfg->K - 1) return launch_prep(cfg, W, k, yy, bb, sigma, 0, B, ws, true, st);
     const float *lw = W + (int64_t)k * L.size();
     const int cur = k & 1;
-    for (int64_t b0 = 0; b0 < B; b0 += ws.chunk) {
+    // chunk buffers and streams: one set on the caller's stream, or two sets on two internal streams (two_streams())
+    Ws sets[2] = {ws, ws};
+    hipStream_t ss[2] = {st, st};
+    const bool dual = ws.set2_offset != 0;
+    if (dual) {
+        Carver c2{reinterpret_cast<char *>(workspace) + ws.set2_offset};
+        carve_second_set(c2, D, ws, &sets[1]);
+        if ((rc = chunk_streams(ss))) return rc;
+        hipEvent_t e0;
+        ADMM_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        ADMM_HIP(hipEventRecord(e0, st));                  // everything the caller has enqueued so far ...
+        ADMM_HIP(hipStreamWaitEvent(ss[0], e0, 0));        // ... happens before the chunks
+        ADMM_HIP(hipStreamWaitEvent(ss[1], e0, 0));
+        ADMM_HIP(hipEventDestroy(e0));
+    }
+    int ci = 0;
+    for (int64_t b0 = 0; b0 < B; b0 += ws.chunk, ++ci) {
         const int64_t nb = (B - b0 < ws.chunk) ? (B - b0) : ws.chunk;
+        const Ws &wc = sets[ci & 1];
+        hipStream_t sc = ss[ci & 1];
         const bool lean = use_lean(D);
         const float2 *phk = ws.phi[cur] + b0 * D;
         const float *hk = ws.h[cur] + b0 * D;
         float2 *Gk = ws.G + b0 * n * n;
         if (k == 0 && use_arrow(D)) {   // Z = 0: arrowhead, no matrix is ever formed
-            if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, ws, false, st, true))) return rc;
-            if ((rc = launch_arrow_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, status, ws, st, lean))) return rc;
+            if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, wc, false, sc, true))) return rc;
+            if ((rc = launch_arrow_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, status, wc, sc, lean))) return rc;
             continue;
         }
-        if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, ws, false, st, false, lean))) return rc;
-        const bool fused = fuse_back(D, ws);
+        if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, wc, false, sc, false, lean))) return rc;
+        const bool fused = fuse_back(D, wc);
         // (D <= 128: the tridiagonalisation's own loader forms A from the lower triangle of Z; D = 256 reads the half image)
-        if ((rc = eig_chunk(D, nb, ws, status, st, !fused, (lean && D <= 128) ? ws.Z + b0 * n * n : nullptr, phk, hk, lw)))
+        if ((rc = eig_chunk(D, nb, wc, status, sc, !fused, (lean && D <= 128) ? ws.Z + b0 * n * n : nullptr, phk, hk, lw)))
             return rc;
-        rc = fused ? launch_back_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, ws, st, lean)
-                   : launch_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, ws, st, lean, eig_dim(D));
+        rc = fused ? launch_back_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, wc, sc, lean)
+                   : launch_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, wc, sc, lean, eig_dim(D));
         if (rc) return rc;
+    }
+    if (dual) {   // the caller's stream continues behind both chunk streams
+        for (int q = 0; q < 2; ++q) {
+            hipEvent_t e1;
+            ADMM_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+            ADMM_HIP(hipEventRecord(e1, ss[q]));
+            ADMM_HIP(hipStreamWaitEvent(st, e1, 0));
+            ADMM_HIP(hipEventDestroy(e1));
+        }
     }
     return launch_rn_sum(B, ws.rn, sum_out ? sum_out : ws.sum, st);
 }

@@ -105,6 +105,7 @@ struct Ws {
     int64_t chunk;            // signals per chunk
     int64_t cap;              // log records per matrix (multiple of 8)
     int64_t total_bytes;
+    int64_t set2_offset;      // byte offset of a second set of chunk buffers (two chunks in flight, api.hip), 0 = none
 };
 
 int64_t eig_chunk_bytes(int D, int64_t chunk);

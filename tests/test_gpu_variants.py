@@ -26,6 +26,7 @@ for name in ("phiest_8x16_K3_perturbed", "admmnet_10x10_K3_default", "phiest_16x
     m = (A.ADMMNet if head else A.PhiEstADMMNet)(M=Nb, N=Nd, L=L, num_layers=K)
     m.load_state_dict(sd)
     m.eval()
+    m.chunk = int(os.environ.get("ADMMNET_TEST_CHUNK", "0"))    # (several eigen-chunks for the variants that act across chunks)
     y, b, s = (torch.from_numpy(z[k]).to(dev) for k in ("y", "b", "sigma"))
     r = m(y, b, s)
     phi = (r[3] if head else r).cpu().numpy()
@@ -45,6 +46,7 @@ VARIANTS = {
     "explicit_q": {"ADMMNET_BACK": "q"},               # D = 256: panel tridiagonalisation, explicit Q + Q W
     "panel_one_stage": {"ADMMNET_PN_SPLIT": "0"},      # D = 256: the whole panel reduction in the 8-wave kernel
     "panel_two_stages": {"ADMMNET_PN_SPLIT": "8"},     # D = 256: panels 0..7 | 8..15 (default: 0..7 | 8..11 | 12..15)
+    "two_streams": {"ADMMNET_STREAMS": "2", "ADMMNET_TEST_CHUNK": "1"},   # two chunks in flight (B = 2 .. 3 at chunk = 1)
     "dc_poison": {"ADMMNET_DC_POISON": "1"},           # D&C ping-pong buffers start as NaN instead of whatever they hold
 }
 
