@@ -165,15 +165,18 @@ def test_dropin_launcher_beats_the_script_directory(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists only in the build container")
-@pytest.mark.parametrize("script", ["main_for_net.py", "test/test_time_net.py", "main.py", "test/test_time_admm.py"])
+@pytest.mark.parametrize("script", ["main_for_net.py", "test/test_time_net.py", "main.py", "test/test_time_admm.py",
+                                    "trainPhi.py", "train.py"])
 def test_dropin_resolves_the_reference_scripts_imports(script, tmp_path):
     """The import block of the reference's own callers, executed under the launcher (run_name != __main__, so main() does
-    not run -- it needs a checkpoint that does not ship): every module they import resolves, the classes are ours."""
+    not run -- it needs a checkpoint / a dataset that do not ship): every module they import resolves, the classes are
+    ours.  For the two training scripts that includes the reference's OWN generate_data.py and loss.py: generate_data
+    star-imports `admm`, which under the launcher is the shim (no cvxpy needed)."""
     code = ("import runpy, sys, os, json\n"
             "from admm_net_amd import dropin\n"
             "here = os.path.dirname(sys.argv[1]); sys.path.insert(0, '/root/reference'); dropin.activate()\n"
             "g = runpy.run_path(sys.argv[1], run_name='imported')\n"
-            "out = {k: getattr(g[k], '__module__', '') for k in ('PhiEstADMMNet', 'admm_for_us', 'alt_peak_search') if k in g}\n"
+            "out = {k: getattr(g[k], '__module__', '') for k in ('PhiEstADMMNet', 'ADMMNet', 'admm_for_us', 'alt_peak_search') if k in g}\n"
             "print(json.dumps(out))\n")
     import json
     env = {**os.environ, "PYTHONPATH": ROOT, "PYTHONDONTWRITEBYTECODE": "1", "MPLBACKEND": "Agg"}
@@ -182,6 +185,45 @@ def test_dropin_resolves_the_reference_scripts_imports(script, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out and all(v.startswith("admm_net_amd") for v in out.values()), out
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists only in the build container")
+def test_reference_dataset_generator_runs_on_the_shims(tmp_path):
+    """trainPhi.py's data side (generate_data.py:352-516, the reference's own file): under the launcher its
+    `from admm import *` / `from utils.mathUtils import *` resolve to the shims, so DatasetGeneratorCreatePhi can label a
+    dataset with phi = admm_for_us(...) without cvxpy, write its .npy splits and hand out the DataLoader batches
+    trainPhi.py:159-162 unpacks.  The phi labels must be what the classical solver gives for the stored (y, b, sigma)."""
+    code = ("import sys, os, json, io, contextlib\n"
+            "sys.path.insert(0, '/root/reference')\n"
+            "from admm_net_amd import dropin\n"
+            "dropin.activate()\n"
+            "import numpy as np, torch\n"
+            "import generate_data as gd\n"
+            "from admm_net_amd import classical\n"
+            "assert gd.__file__.startswith('/root/reference') and gd.admm_for_us.__module__.startswith('admm_net_amd')\n"
+            "np.random.seed(0)\n"
+            "with contextlib.redirect_stdout(io.StringIO()):\n"
+            "    g = gd.DatasetGeneratorCreatePhi(Nb=4, Nd=5, L_max=3, data_dir=sys.argv[1])\n"
+            "    g.generate_complete_dataset(total_samples=10)\n"
+            "    dl = g.create_pytorch_dataloader(batch_size=4, split='train', shuffle=False)\n"
+            "    batch = next(iter(dl))\n"
+            "    y, b, sigma, phi = batch[0], batch[1], batch[6], batch[7]\n"
+            "    errs = []\n"
+            "    for i in range(y.shape[0]):\n"
+            "        want, it = classical.admm_for_us(y[i].numpy().astype(np.complex128), b[i].numpy().astype(np.complex128), 5, 4, 1,\n"
+            "                                         float(sigma[i]), {'eta_abs': 1e-7, 'eta_rel': 1e-7, 'max_iter': 100})\n"
+            "        errs.append(float(np.abs(phi[i].numpy() - want).max() / np.abs(want).max()))\n"
+            "print(json.dumps({'shapes': [list(t.shape) for t in batch], 'dtypes': [str(t.dtype) for t in batch], 'err': max(errs),\n"
+            "                  'files': sorted(os.listdir(sys.argv[1]))}))\n")
+    import json
+    env = {**os.environ, "PYTHONPATH": ROOT, "PYTHONDONTWRITEBYTECODE": "1", "MPLBACKEND": "Agg"}
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "data")], cwd=str(tmp_path), env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["shapes"][0] == [4, 20] and out["shapes"][7] == [4, 20] and out["dtypes"][7] == "torch.complex64"
+    assert out["err"] < 1e-5, out          # (labels are stored as complex64 from a complex64-rounded scene)
+    assert any(f.endswith(".npy") or f.endswith(".npz") or f.endswith(".json") for f in out["files"]), out["files"]
 
 
 def test_synth_batch_shapes_and_model():
