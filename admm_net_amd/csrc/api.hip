@@ -166,6 +166,18 @@ static void carve_chunk(Carver &c, int Dact, int64_t chunk, Ws *ws) {
         ws->Wdc = nullptr;
         ws->VT = ws->QV;   // the rotation replay works in place
     }
+    ws->spec_mat = nullptr;
+    ws->spec_vec = nullptr;
+    ws->spec_val = nullptr;
+    ws->spec_flag = nullptr;
+    ws->skip = nullptr;
+    if (use_spectral()) {   // (in the layer's own dimension: the fast path never sees the padded image)
+        const int64_t na = Dact + 1;
+        ws->spec_mat = c.take<float2>(2 * chunk * na * na);
+        ws->spec_vec = c.take<float2>(chunk * 2 * na);
+        ws->spec_val = c.take<double>(chunk * 8);
+        ws->spec_flag = c.take<int>(chunk);
+    }
 }
 
 int64_t eig_chunk_bytes(int D, int64_t chunk) {
@@ -500,11 +512,18 @@ int admmnet_layer_front(const admmnet_cfg *cfg, const float *W, int32_t k, const
         }
         if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, wc, false, sc, false, lean))) return rc;
         const bool fused = fuse_back(D, wc);
+        Ws wf = wc;
+        if (use_spectral() && wc.spec_flag && lean && (D > 128 || fused)) {
+            // opt-in: G as a matrix function where the spectrum allows it (checked per matrix); the kernels below then only
+            // run the matrices it flagged
+            if ((rc = launch_spectral(D, nb, lw, phk, hk, ws.Z + b0 * n * n, Gk, ws.rn + b0, wc, status, sc, true))) return rc;
+            wf.skip = wc.spec_flag;
+        }
         // (D <= 128: the tridiagonalisation's own loader forms A from the lower triangle of Z; D = 256 reads the half image)
-        if ((rc = eig_chunk(D, nb, wc, status, sc, !fused, (lean && D <= 128) ? ws.Z + b0 * n * n : nullptr, phk, hk, lw)))
+        if ((rc = eig_chunk(D, nb, wf, status, sc, !fused, (lean && D <= 128) ? ws.Z + b0 * n * n : nullptr, phk, hk, lw)))
             return rc;
-        rc = fused ? launch_back_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, wc, sc, lean)
-                   : launch_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, wc, sc, lean, eig_dim(D));
+        rc = fused ? launch_back_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, wf, sc, lean)
+                   : launch_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, wf, sc, lean, eig_dim(D));
         if (rc) return rc;
     }
     if (dual) {   // the caller's stream continues behind both chunk streams

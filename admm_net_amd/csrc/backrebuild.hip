@@ -47,7 +47,7 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     int D, const float *__restrict__ lw, const float *__restrict__ Wbuf, const float *__restrict__ QT,
     const float *__restrict__ wv, const float *__restrict__ w0v, const float2 *__restrict__ phi,
     const float *__restrict__ h, float2 *__restrict__ G, float *__restrict__ rn,
-    unsigned long long *__restrict__ ptime, int64_t wt_off, int lower_only) {
+    unsigned long long *__restrict__ ptime, int64_t wt_off, int lower_only, const int *__restrict__ skip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // developer phase timer (ADMMNET_BR_TIMING=1): cycles of thread 0 between marks
     long long t_prev = ptime ? clock64() : 0;
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(BR_THREADS, 1) void back_rebuild_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, kh = lane >> 5;
     const int64_t b = blockIdx.x;
+    if (skip && skip[b] == 0) return;   // (uniform) this matrix' G is already there: spectral.hip
     float *big = reinterpret_cast<float *>(smem);
     const size_t bigf = br_slab_floats(g) > g.vt_floats() ? br_slab_floats(g) : g.vt_floats();
     float *fs = big + bigf;                          // [n+1] f(lambda)
@@ -266,7 +267,7 @@ int launch_back_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, c
         ADMM_HIP(hipMemsetAsync(ptime, 0, 16 * sizeof(unsigned long long), st));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(BR_THREADS), lds, st, D, lw, ws.Wdc, ws.QV,
-                       ws.w, ws.w0, phi, h, G, rn, ptime, dc_final_offset(D + 1), lower_only ? 1 : 0);
+                       ws.w, ws.w0, phi, h, G, rn, ptime, dc_final_offset(D + 1), lower_only ? 1 : 0, ws.skip);
     ADMM_HIP(hipGetLastError());
     if (timing) {
         unsigned long long hb[16];

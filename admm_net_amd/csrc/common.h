@@ -106,6 +106,13 @@ struct Ws {
     int64_t cap;              // log records per matrix (multiple of 8)
     int64_t total_bytes;
     int64_t set2_offset;      // byte offset of a second set of chunk buffers (two chunks in flight, api.hip), 0 = none
+    // matrix-function fast path of the G-layer (spectral.hip, ADMMNET_SPECTRAL=1; null otherwise)
+    float2 *spec_mat;         // [2][chunk][n][n]: A (then E in place), E^2
+    float2 *spec_vec;         // [chunk][2][n] the two outlier eigenvectors
+    double *spec_val;         // [chunk][8] lam0, lam1, c, residuals, trace
+    int *spec_flag;           // [chunk] 1 = this matrix takes the eigen-pipeline after all
+    const int *skip;          // per-matrix filter of the eigen-pipeline kernels: workgroups of matrices with skip[b] == 0 leave
+                              // at once (null: every matrix runs)
 };
 
 int64_t eig_chunk_bytes(int D, int64_t chunk);
@@ -180,6 +187,10 @@ int launch_spectrum_tables(const double *taus, int nx, int xbase, const double *
 int launch_spectrum_main(const float2 *phi, int64_t B, int xbase, int ybase, const double2 *tabD, int nx,
                          const double2 *tabS, int ny, double *out, hipStream_t st);
 
+// spectral.hip
+bool use_spectral();
+int launch_spectral(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, const float2 *Z, float2 *G,
+                    float *rn, const Ws &ws, int32_t *status, hipStream_t st, bool lower_only);
 // vdvh.hip (training route)
 int launch_vdvh(int n, int64_t nb, const float2 *V, const float *d, float2 *out, hipStream_t st);
 int launch_vhsv(int n, int64_t nb, const float2 *V, const float2 *S, float *q, hipStream_t st);

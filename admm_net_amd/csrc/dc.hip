@@ -326,10 +326,11 @@ __global__ __launch_bounds__(DC_THREADS, OCC) void dc_kernel(int n, const float 
                                                         float *__restrict__ wout, float *__restrict__ w0out,
                                                         int *__restrict__ logn, int32_t *__restrict__ status,
                                                         unsigned long long *__restrict__ ptime, int rowmajor, int poison,
-                                                        int2 *__restrict__ wmap) {
+                                                        int2 *__restrict__ wmap, const int *__restrict__ skip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int64_t bm = blockIdx.x;
+    if (skip && skip[bm] == 0) return;   // (uniform) this matrix' G is already there: spectral.hip
     const DcCarve cv(smem, n);
     DcShared &sh = *cv.sh;
     const int NP = cv.NP;
@@ -919,7 +920,7 @@ int launch_dc(int n, int64_t nb, const Ws &ws, int32_t *status, hipStream_t st, 
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(DC_THREADS), lds, st, n, ws.dT, ws.eT, ws.Wdc, ws.w,
                        ws.w0, ws.logn, status, ptime, rowmajor ? 1 : 0, poison ? 1 : 0,
-                       (colmap && ws.Wmap && dc_leaf_count(n) > 1) ? ws.Wmap : nullptr);
+                       (colmap && ws.Wmap && dc_leaf_count(n) > 1) ? ws.Wmap : nullptr, ws.skip);
     ADMM_HIP(hipGetLastError());
     if (timing) {
         unsigned long long h[96];

@@ -239,6 +239,10 @@ int launch_rebuild(int D, int64_t nb, const float *lw, const float2 *phi, const 
         set_error("rebuild: no kernel for a %d-image holding D=%d", image_dim, D);
         return ADMMNET_E_ARG;
     }
+    if (ws.skip) {
+        set_error("rebuild: the per-tile kernel has no per-matrix filter (ADMMNET_SPECTRAL=1 with ADMMNET_REBUILD=tiles)");
+        return ADMMNET_E_ARG;
+    }
     const size_t lds = sizeof(float) * (3 * ((n + 4) & ~3) + 2 * D + 8);
     hipLaunchKernelGGL(rebuild_kernel, dim3((unsigned)nb), dim3(RB_THREADS), lds, st, D, lw, ws.VT, ws.w,
                        ws.w0, phi, h, G, rn, lower_only ? 1 : 0);

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(RG_THREADS, 2) void rebuild_big_kernel(const float 
                                                                     const float *__restrict__ w0v,
                                                                     const float2 *__restrict__ phi,
                                                                     const float *__restrict__ h, float2 *__restrict__ G,
-                                                                    float *__restrict__ rn, int lower_only, int Da) {
+                                                                    float *__restrict__ rn, int lower_only, int Da,
+                                                                    const int *__restrict__ skip) {
     __shared__ float slab[2][RG_KS][RG_PITCH];
     __shared__ float fs[264], w0f[264], z0s[264];
     __shared__ float redb[8];
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(RG_THREADS, 2) void rebuild_big_kernel(const float 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, kh = lane >> 5;
     const int64_t b = blockIdx.x;
+    if (skip && skip[b] == 0) return;   // (uniform) this matrix' G is already there: spectral.hip
     const LayerLayout L{Da};
     const float thr = lw[S_THR];
     const float *vn = lw + L.off_vn();
@@ -200,7 +202,7 @@ int launch_rebuild_big(int D, int64_t nb, const float *lw, const float2 *phi, co
         return ADMMNET_E_ARG;
     }
     hipLaunchKernelGGL(rebuild_big_kernel, dim3((unsigned)nb), dim3(RG_THREADS), 0, st, lw, ws.VT, ws.w, ws.w0, phi, h, G,
-                       rn, lower_only ? 1 : 0, D);
+                       rn, lower_only ? 1 : 0, D, ws.skip);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }

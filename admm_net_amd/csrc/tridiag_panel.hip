@@ -201,7 +201,8 @@ template <int NT, bool HEAD, bool TIMING>
 __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__restrict__ Mbuf, float *__restrict__ dT,
                                                                    float *__restrict__ eT, float2 *__restrict__ Tfac,
                                                                    float2 *__restrict__ Tail, int pstop, int zfill,
-                                                                   unsigned long long *__restrict__ tdbg) {
+                                                                   unsigned long long *__restrict__ tdbg,
+                                                                   const int *__restrict__ skip) {
     static_assert(NT % 4 == 0 && NT <= 16 && (HEAD == (NT == 16)), "stage geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Shared = PnShared<NT>;
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(32 * NT, 2) void tridiag_panel_kernel(float2 *__res
     int c16 = c16_0, g = g_0;
     int IA = wave, IB = NT - 1 - wave;
     const int64_t bm = blockIdx.x;
+    if (skip && skip[bm] == 0) return;   // (uniform) this matrix' G is already there: spectral.hip
     float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
     float *dcol = dT + bm * n, *ecol = eT + bm * n;
     float2 *tail = Tail + bm * (PN_TAIL_TILES * 256);
@@ -801,7 +803,7 @@ static int pn_launch_stage(int64_t nb, const Ws &ws, int pstop, unsigned long lo
     ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_panel_kernel<NT, HEAD, TIMING>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((tridiag_panel_kernel<NT, HEAD, TIMING>), dim3((unsigned)nb), dim3(32 * NT), lds, st, ws.Mbuf,
-                       ws.dT, ws.eT, ws.Tfac, ws.Tail, pstop, use_wy_back(PN_D) ? 0 : 1, tdbg);
+                       ws.dT, ws.eT, ws.Tfac, ws.Tail, pstop, use_wy_back(PN_D) ? 0 : 1, tdbg, ws.skip);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }

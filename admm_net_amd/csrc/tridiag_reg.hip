@@ -385,11 +385,13 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void tridiag_reg_kernel(int D, flo
                                                                     const float2 *__restrict__ Zlow,
                                                                     const float2 *__restrict__ phi,
                                                                     const float *__restrict__ hvec,
-                                                                    const float *__restrict__ lw) {
+                                                                    const float *__restrict__ lw,
+                                                                    const int *__restrict__ skip) {
     __shared__ TrShared<NA> sh;
     const int tid = threadIdx.x;
     const int tj = tid & 15, ti = tid >> 4;
     const int64_t bm = blockIdx.x;
+    if (skip && skip[bm] == 0) return;   // (uniform) this matrix' G is already there: spectral.hip
     const int n = D + 1;
     float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
     const float2 *ag = Mg + (int64_t)D * D;
@@ -535,20 +537,20 @@ static int launch_tr(int D, int64_t nb, const Ws &ws, hipStream_t st, const floa
         if (occ3 && pad == 0) {
             if (Zlow)
                 hipLaunchKernelGGL((tridiag_reg_kernel<NA, true, 3>), dim3((unsigned)nb), dim3(TR_THREADS), 0, st, D, ws.Mbuf,
-                                   ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw);
+                                   ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw, ws.skip);
             else
                 hipLaunchKernelGGL((tridiag_reg_kernel<NA, false, 3>), dim3((unsigned)nb), dim3(TR_THREADS), 0, st, D, ws.Mbuf,
-                                   ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw);
+                                   ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw, ws.skip);
             ADMM_HIP(hipGetLastError());
             return ADMMNET_OK;
         }
     }
     if (Zlow)
         hipLaunchKernelGGL((tridiag_reg_kernel<NA, true>), dim3((unsigned)nb), dim3(TR_THREADS), pad, st, D, ws.Mbuf,
-                           ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw);
+                           ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw, ws.skip);
     else
         hipLaunchKernelGGL((tridiag_reg_kernel<NA, false>), dim3((unsigned)nb), dim3(TR_THREADS), pad, st, D, ws.Mbuf,
-                           ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw);
+                           ws.QV, ws.dT, ws.eT, Zlow, phi, h, lw, ws.skip);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }

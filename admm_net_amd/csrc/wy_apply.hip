@@ -39,7 +39,7 @@ __global__ __launch_bounds__(WY_THREADS, 3) void wy_apply_kernel(const float2 *_
                                                                  const float2 *__restrict__ Tfac,
                                                                  const float *__restrict__ Wbuf,
                                                                  const int2 *__restrict__ Wmap, float *__restrict__ VT,
-                                                                 int nb) {
+                                                                 int nb, const int *__restrict__ skip) {
     __shared__ WyShared sh;
     constexpr int D = WY_D, n = D + 1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(WY_THREADS, 3) void wy_apply_kernel(const float2 *_
     const int xcd = blockIdx.x & 7, iq = blockIdx.x >> 3;
     const int64_t bm = (int64_t)(iq >> 2) * 8 + xcd;
     if (bm >= nb) return;                          // (uniform; the grid is padded to a multiple of 8 matrices)
+    if (skip && skip[bm] == 0) return;             // (uniform) this matrix' G is already there: spectral.hip
     const int cb = 4 * (iq & 3) + wave;            // column block of this wave: eigenvectors 16 cb .. 16 cb + 15
     const int col = 16 * cb + c16;
     const float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
@@ -187,10 +188,12 @@ __global__ __launch_bounds__(WY_THREADS, 3) void wy_apply_kernel(const float2 *_
 constexpr int WL_BATCH = 8;
 
 __global__ __launch_bounds__(64) void wy_lastcol_kernel(const float2 *__restrict__ Mbuf, const float *__restrict__ Wbuf,
-                                                        const int2 *__restrict__ Wmap, float *__restrict__ VT) {
+                                                        const int2 *__restrict__ Wmap, float *__restrict__ VT,
+                                                        const int *__restrict__ skip) {
     constexpr int D = WY_D, n = D + 1;
     const int lane = threadIdx.x;
     const int64_t bm = blockIdx.x;
+    if (skip && skip[bm] == 0) return;
     const float2 *Mg = Mbuf + bm * ((int64_t)D * D + D + 1);
     const float2 *taus = Mg + (int64_t)D * D;
     int2 wm = Wmap[bm * n + D];                                  // eigenvector 256 through the column map (see wy_apply_kernel)
@@ -261,9 +264,9 @@ int launch_wy_apply(int D, int64_t nb, const Ws &ws, hipStream_t st) {
         return ADMMNET_E_ARG;
     }
     hipLaunchKernelGGL(wy_apply_kernel, dim3((unsigned)(4 * ((nb + 7) & ~(int64_t)7))), dim3(WY_THREADS), 0, st, ws.Mbuf,
-                       ws.Tfac, ws.Wdc, ws.Wmap, ws.VT, (int)nb);
+                       ws.Tfac, ws.Wdc, ws.Wmap, ws.VT, (int)nb, ws.skip);
     ADMM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(wy_lastcol_kernel, dim3((unsigned)nb), dim3(64), 0, st, ws.Mbuf, ws.Wdc, ws.Wmap, ws.VT);
+    hipLaunchKernelGGL(wy_lastcol_kernel, dim3((unsigned)nb), dim3(64), 0, st, ws.Mbuf, ws.Wdc, ws.Wmap, ws.VT, ws.skip);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }

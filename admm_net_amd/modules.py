@@ -252,7 +252,10 @@ class _FusedBase(nn.Module):
                                          _ptr(head), _ptr(ws), ws.numel(), _ptr(status), stream)
             _lib.check(rc, "admmnet_forward_f32")
             if self.check_status:
-                bad = int(status[0].item())
+                # [0] eigensolver failures; with ADMMNET_SPECTRAL=1: [1] matrix-layers that took the eigensolver after all,
+                # [2] matrix-layers evaluated as a matrix function (csrc/spectral.hip)
+                self.last_status = status.tolist()
+                bad = int(self.last_status[0])
                 if bad:
                     raise _lib.AdmmNetError(f"eigensolver failed to converge on {bad} matrices")
         out_dev = y.device

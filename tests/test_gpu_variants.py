@@ -48,6 +48,9 @@ VARIANTS = {
     "panel_two_stages": {"ADMMNET_PN_SPLIT": "8"},     # D = 256: panels 0..7 | 8..15 (default: 0..7 | 8..11 | 12..15)
     "two_streams": {"ADMMNET_STREAMS": "2", "ADMMNET_TEST_CHUNK": "1"},   # two chunks in flight (B = 2 .. 3 at chunk = 1)
     "dc_poison": {"ADMMNET_DC_POISON": "1"},           # D&C ping-pong buffers start as NaN instead of whatever they hold
+    # the G-layer as a matrix function wherever the per-matrix checks allow it, the eigensolver on the rest (spectral.hip)
+    "spectral": {"ADMMNET_SPECTRAL": "1"},
+    "spectral_two_streams": {"ADMMNET_SPECTRAL": "1", "ADMMNET_STREAMS": "2", "ADMMNET_TEST_CHUNK": "1"},
 }
 
 
