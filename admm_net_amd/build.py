@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadmmnet_hip.so")
 SOURCES = ["api.hip", "prep.hip", "tridiag.hip", "tridiag_reg.hip", "tridiag_big.hip", "tridiag_panel.hip", "wy_apply.hip", "tql.hip", "rotapply.hip", "dc.hip", "rebuild.hip", "rebuild_big.hip", "backrebuild.hip", "vgemm_big.hip", "arrow.hip",
-           "zstep.hip", "head.hip", "spectrum.hip", "peaks.hip", "synth.hip", "vdvh.hip", "spectral.hip"]
+           "zstep.hip", "head.hip", "spectrum.hip", "peaks.hip", "synth.hip", "vdvh.hip", "spectral.hip", "spectral_fused.hip"]
 HEADERS = ["common.h", "eig_core.h", "dc_core.h", "arrow_core.h", "rebuild_lds.h", "lane_reduce.h", os.path.join("..", "..", "include", "admmnet.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-file extras: the SLP vectoriser packs the rotation replay into v_pk_* ops that need a

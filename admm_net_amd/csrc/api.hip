@@ -173,9 +173,11 @@ static void carve_chunk(Carver &c, int Dact, int64_t chunk, Ws *ws) {
     ws->skip = nullptr;
     if (use_spectral()) {   // (in the layer's own dimension: the fast path never sees the padded image)
         const int64_t na = Dact + 1;
-        ws->spec_mat = c.take<float2>(2 * chunk * na * na);
-        ws->spec_vec = c.take<float2>(chunk * 2 * na);
-        ws->spec_val = c.take<double>(chunk * 8);
+        if (!use_spectral_fused()) {   // (the multi-kernel form keeps A / E and E^2 in memory)
+            ws->spec_mat = c.take<float2>(2 * chunk * na * na);
+            ws->spec_vec = c.take<float2>(chunk * 2 * na);
+            ws->spec_val = c.take<double>(chunk * 8);
+        }
         ws->spec_flag = c.take<int>(chunk);
     }
 }

@@ -189,6 +189,9 @@ int launch_spectrum_main(const float2 *phi, int64_t B, int xbase, int ybase, con
 
 // spectral.hip
 bool use_spectral();
+bool use_spectral_fused();   // spectral_fused.hip: the whole evaluation in one kernel (default when the path is on)
+int launch_spectral_fused(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, const float2 *Z, float2 *G,
+                          float *rn, int *flag, int32_t *status, float tol, hipStream_t st);
 int launch_spectral(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, const float2 *Z, float2 *G,
                     float *rn, const Ws &ws, int32_t *status, hipStream_t st, bool lower_only);
 // vdvh.hip (training route)

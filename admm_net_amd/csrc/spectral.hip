@@ -434,6 +434,14 @@ int launch_spectral(int D, int64_t nb, const float *lw, const float2 *phi, const
     ProfScope _prof(KC_REBUILD, st);
     if (nb <= 0) return ADMMNET_OK;
     const int n = D + 1;
+    static const float tol = getenv("ADMMNET_SPECTRAL_TOL") ? (float)atof(getenv("ADMMNET_SPECTRAL_TOL")) : 3e-7f;
+    if (use_spectral_fused()) {
+        if (!ws.spec_flag || !lower_only) {
+            set_error("spectral: the fused kernel needs the flag buffer and the lower-triangle state");
+            return ADMMNET_E_WORKSPACE;
+        }
+        return launch_spectral_fused(D, nb, lw, phi, h, Z, G, rn, ws.spec_flag, status, tol, st);
+    }
     if (!ws.spec_flag || !ws.spec_vec || !ws.spec_val || !ws.spec_mat) {
         set_error("spectral: workspace without the fast-path buffers");
         return ADMMNET_E_WORKSPACE;
@@ -451,7 +459,6 @@ int launch_spectral(int D, int64_t nb, const float *lw, const float2 *phi, const
     ADMM_HIP(hipGetLastError());
     hipLaunchKernelGGL(sp_square_kernel, dim3((unsigned)nb), dim3(SP_THREADS), 0, st, n, A, E2, ws.spec_val);
     ADMM_HIP(hipGetLastError());
-    static const float tol = getenv("ADMMNET_SPECTRAL_TOL") ? (float)atof(getenv("ADMMNET_SPECTRAL_TOL")) : 3e-7f;
     hipLaunchKernelGGL(sp_assemble_kernel, dim3((unsigned)nb), dim3(SP_THREADS), sizeof(float2) * 2 * n, st, D, lw, A, E2,
                        ws.spec_vec, ws.spec_val, phi, h, G, rn, ws.spec_flag, status, lower_only ? 1 : 0, tol);
     ADMM_HIP(hipGetLastError());
