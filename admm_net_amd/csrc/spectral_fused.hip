@@ -1,9 +1,9 @@
 // spectral_fused.hip -- the matrix-function evaluation of the G-layer (spectral.hip has the mathematics and the checks) as ONE
-// kernel per chunk: a 512-thread workgroup per matrix reads the lower triangle of the state Z (six times, five of them from the
+// kernel per chunk: a 768-thread workgroup per matrix reads the lower triangle of the state Z (six times, five of them from the
 // L2 / the memory-side cache), and writes the lower triangle of G once.  Nothing else goes through HBM -- no n x n scratch matrix.
 //
 //   P1  the two outlier eigenpairs by subspace iteration, A x formed from the lower triangle of Z on the fly
-//       (A = [[diag h, phi], [phi^H, corner]] - Z / rho is never stored): wave w owns the rows i = w mod 8, lane l the columns
+//       (A = [[diag h, phi], [phi^H, corner]] - Z / rho is never stored): wave w owns the rows i = w mod 12, lane l the columns
 //       l + 64 m; the row part sum_{j <= i} A_ij x_j is reduced across the wave, the mirrored part y_j += conj(A_ij) x_i stays in
 //       lane-private accumulators until the end of the pass.  Both vectors ride the same pass.  fp32 throughout.
 //   P2  E = A - c I - sum_k mu_k v_k v_k^H in slabs of 32 rows, rounded to bf16 and written to LDS TRANSPOSED (ET[j][k]), so that
@@ -11,12 +11,13 @@
 //       layout.  bf16 is enough HERE AND ONLY HERE: a2 E^2 is the second-order term, |a2| ||E||^2 <= 1e-4 of the result's scale is
 //       checked per matrix (else: eigen-pipeline), so the 2^-9 relative rounding of the operands moves G by < 4e-7 of its scale.
 //   P3  v_mfma_f32_32x32x16_bf16 on the resident accumulators: the 32 x 32 tiles of the lower triangle of the D x D interior are
-//       dealt to the eight waves (at most five per wave, D = 256) and stay in registers over all slabs; the border row (index D, the
+//       dealt to the twelve waves (three per wave at D = 256, consecutive ones: they share a tile row) and stay in registers over all slabs; the border row (index D, the
 //       arrow) of E^2 is accumulated by the vector ALUs from the same slabs.
 //   P4  ||E^2||_F -> delta, the quadratic model of f and its checks (spectral.hip), then
 //       G = (a0 - a1 c) I + a1 A + a2 E^2 + sum_k (f(lam_k) - a0 - a1 mu_k) v_k v_k^H  straight from the accumulator layout
 //       (A once more from Z), and ||G - C_z||_F for the Z-layer.
 // Matrices that fail a check are flagged and leave G untouched: the eigen-pipeline runs them (Ws::skip).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -24,7 +25,7 @@
 
 namespace admmnet {
 
-constexpr int SF_THREADS = 512, SF_WAVES = 8;
+constexpr int SF_THREADS = 768, SF_WAVES = 12;   // three waves per SIMD, 168 registers each: every phase is latency-bound
 constexpr int SF_PITCH = 40;   // bf16 per slab row: 32 k-values + 8 of padding (80 bytes: 16-byte aligned, spreads the banks)
 constexpr int SF_MAXM = 5;     // column chunks of 64 per row (n <= 257 + ...: ceil(257 / 64))
 
@@ -70,6 +71,27 @@ __device__ __forceinline__ void sf_block_sum4(float &a, float &b, float &c, floa
     a = s[0]; b = s[1]; c = s[2]; d = s[3];
 }
 
+// six values in one round (two barriers)
+__device__ __forceinline__ void sf_block_sum8(float &a, float &b, float &c, float &d, float &e, float &f, float *red /* [8][SF_WAVES] */) {
+    const float t = sf_reduce4(a, b, c, d), u = sf_reduce4(e, f, 0.f, 0.f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((lane & 15) == 0) {
+        red[(lane >> 4) * SF_WAVES + wave] = t;
+        red[(4 + (lane >> 4)) * SF_WAVES + wave] = u;
+    }
+    __syncthreads();
+    float s[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < SF_WAVES; ++w) v += red[q * SF_WAVES + w];
+        s[q] = v;
+    }
+    a = s[0]; b = s[1]; c = s[2]; d = s[3]; e = s[4]; f = s[5];
+}
+
 __device__ inline double sf_eig_map(double w, double thr, const float *vn) {   // rebuild_lds.h: br_eig_map, in double
     const double x = w - thr;
     const double base = x > 20.0 ? x : log1p(exp(x));
@@ -99,7 +121,7 @@ struct SfCarve {
     }
     __host__ __device__ static size_t bytes(int n) {
         const size_t NP = np_of(n), NJ = nj_of(n);
-        const size_t fixed = sizeof(float2) * 6 * NP + sizeof(float) * NP + sizeof(float) * 64 + sizeof(float) * 16 +
+        const size_t fixed = sizeof(float2) * 6 * NP + sizeof(float) * NP + sizeof(float) * 96 + sizeof(float) * 16 +
                              sizeof(double) * 16 + sizeof(int) * 4;
         const size_t part = sizeof(float2) * SF_WAVES * 2 * NP;
         const size_t slab = sizeof(unsigned short) * 2 * NJ * SF_PITCH;
@@ -112,14 +134,17 @@ struct SfCarve {
         X0 = reinterpret_cast<float2 *>(sc + 16);
         X1 = X0 + NP; Y0 = X1 + NP; Y1 = Y0 + NP; ph = Y1 + NP; Ob = ph + NP;
         hh = reinterpret_cast<float *>(Ob + NP);
-        red = hh + NP;                                              // 64 floats
-        coef = red + 64;                                            // 16 floats
+        red = hh + NP;                                              // 96 floats
+        coef = red + 96;                                            // 16 floats
         flags = reinterpret_cast<int *>(coef + 16);                 // 4 ints
-        char *u = reinterpret_cast<char *>(flags + 4);
-        u = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(u) + 15) & ~(uintptr_t)15);
+        // (offsets, not pointer arithmetic through integers: the compiler must keep seeing LDS addresses -- a round trip through
+        //  uintptr_t turned every slab access into a flat_load with a 64-bit address that it then spilled around the MFMAs)
+        const int fixed = (int)(sizeof(double) * 16 + sizeof(float2) * 6 * NP + sizeof(float) * NP + sizeof(float) * 112 +
+                                sizeof(int) * 4);
+        char *u = smem + ((fixed + 15) & ~15);
         part = reinterpret_cast<float2 *>(u);
         ETre = reinterpret_cast<unsigned short *>(u);
-        ETim = ETre + (size_t)NJ * SF_PITCH;
+        ETim = ETre + NJ * SF_PITCH;
     }
 };
 
@@ -139,8 +164,17 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
                                                                  const float *__restrict__ h, const float2 *__restrict__ Zg,
                                                                  float2 *__restrict__ G, float *__restrict__ rn,
                                                                  int *__restrict__ flag, int32_t *__restrict__ status, float tol,
-                                                                 int iters) {
+                                                                 int iters, unsigned long long *__restrict__ ptime) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // developer phase timer (ADMMNET_SF_TIMING=1): cycles of thread 0 between marks
+    long long t_prev = ptime ? clock64() : 0;
+    auto mark = [&](int id) {
+        if (ptime && threadIdx.x == 0) {
+            const long long t_now = clock64();
+            atomicAdd(&ptime[id], (unsigned long long)(t_now - t_prev));
+            t_prev = t_now;
+        }
+    };
     const int n = D + 1;
     const SfCarve cv(smem, n);
     const int NP = cv.NP;
@@ -172,6 +206,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
     }
     __syncthreads();
 
+    mark(0);
     // ---- P1: subspace iteration ---------------------------------------------------------------------------------------------
     float2 phr[SF_MAXM];
 #pragma unroll
@@ -193,7 +228,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             c1[m] = v2f{0.f, 0.f};
         }
         float trl = 0.f;
-        float2 zc[SF_MAXM], zn[SF_MAXM];
+        float2 za[SF_MAXM], zb[SF_MAXM], zc[SF_MAXM], zd[SF_MAXM];
         auto load_row = [&](int i, float2(&z)[SF_MAXM]) {
 #pragma unroll
             for (int m = 0; m < SF_MAXM; ++m) {
@@ -201,9 +236,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
                 z[m] = (i < n && j <= i) ? Z[(int64_t)i * n + j] : make_float2(0.f, 0.f);
             }
         };
-        load_row(wave, zc);
-        for (int i = wave; i < n; i += SF_WAVES) {
-            load_row(i + SF_WAVES, zn);
+        auto proc_row = [&](int i, const float2(&zc)[SF_MAXM]) {
             const v2f xi0 = pk2(cv.X0[i]), xi1 = pk2(cv.X1[i]);
             const float hi = cv.hh[i];
             v2f r0 = {0.f, 0.f}, r1 = {0.f, 0.f};
@@ -227,8 +260,20 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
                 float *dst = reinterpret_cast<float *>((lane & 32) ? cv.Y1 : cv.Y0);
                 dst[2 * i + ((lane >> 4) & 1)] = t;
             }
+        };
+        // two rows per trip, the next two in flight behind them (the loads are the latency that bounds this phase)
+        load_row(wave, za);
+        load_row(wave + SF_WAVES, zb);
+        for (int i = wave; i < n; i += 2 * SF_WAVES) {
+            load_row(i + 2 * SF_WAVES, zc);
+            load_row(i + 3 * SF_WAVES, zd);
+            proc_row(i, za);
+            if (i + SF_WAVES < n) proc_row(i + SF_WAVES, zb);
 #pragma unroll
-            for (int m = 0; m < SF_MAXM; ++m) zc[m] = zn[m];
+            for (int m = 0; m < SF_MAXM; ++m) {
+                za[m] = zc[m];
+                zb[m] = zd[m];
+            }
         }
         // the mirrored part: per-wave partial sums, then one add per column
 #pragma unroll
@@ -245,6 +290,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             trace = (double)trl;
         }
         __syncthreads();
+        mark(1);
         float2 x0e = make_float2(0.f, 0.f), x1e = x0e, y0e = x0e, y1e = x0e;
         if (tid < n) {
             y0e = cv.Y0[tid];
@@ -262,31 +308,27 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         float h00 = x0e.x * y0e.x + x0e.y * y0e.y, h11 = x1e.x * y1e.x + x1e.y * y1e.y;
         float h01r = x0e.x * y1e.x + x0e.y * y1e.y, h01i = x0e.x * y1e.y - x0e.y * y1e.x;
         sf_block_sum4(h00, h11, h01r, h01i, cv.red);
-        // closed-form eigen-decomposition of [[h00, h01], [conj(h01), h11]] (every thread, double)
-        float ct, st, er, ei;
+        // closed-form eigen-decomposition of [[h00, h01], [conj(h01), h11]] (every thread; fp32 like the sums it is made of)
+        float ct = 1.f, st = 0.f, er = 1.f, ei = 0.f;
         {
-            const double a = h00, d = h11, br_ = h01r, bi_ = h01i;
-            const double ab = sqrt(br_ * br_ + bi_ * bi_);
-            const double dif = 0.5 * (a - d), rad = sqrt(dif * dif + ab * ab);
-            const double dl0 = 0.5 * (a + d) - rad, dl1 = 0.5 * (a + d) + rad;
+            const float ab = sqrtf(h01r * h01r + h01i * h01i);
+            const float dif = 0.5f * (h00 - h11), rad = sqrtf(dif * dif + ab * ab);
+            l0 = 0.5f * (h00 + h11) - rad;
+            l1 = 0.5f * (h00 + h11) + rad;
             // eigenvector of the larger eigenvalue of [[a, |b|], [|b|, d]]: (cos t, sin t), the better-conditioned of its two forms
-            const double vx = dif >= 0.0 ? dif + rad : ab, vy = dif >= 0.0 ? ab : rad - dif;
-            const double nrm = sqrt(vx * vx + vy * vy);
-            double dct = 1.0, dst = 0.0, der = 1.0, dei = 0.0;
-            if (nrm > 0.0) {
-                dct = vx / nrm;
-                dst = vy / nrm;
+            const float vx = dif >= 0.f ? dif + rad : ab, vy = dif >= 0.f ? ab : rad - dif;
+            const float nrm = sqrtf(vx * vx + vy * vy);
+            if (nrm > 0.f) {
+                ct = vx / nrm;
+                st = vy / nrm;
             }
-            if (ab > 0.0) {
-                der = br_ / ab;
-                dei = -bi_ / ab;
+            if (ab > 0.f) {
+                er = h01r / ab;
+                ei = -h01i / ab;
             }
-            ct = (float)dct; st = (float)dst; er = (float)der; ei = (float)dei;
-            l0 = (float)dl0; l1 = (float)dl1;
-            const double dc = (trace - dl0 - dl1) / (double)(n - 2);
-            cf = (float)dc;
+            cf = (float)((trace - (double)l0 - (double)l1) / (double)(n - 2));
             if (tid == 0) {
-                cv.sc[0] = dl0; cv.sc[1] = dl1; cv.sc[2] = dc;
+                cv.sc[0] = l0; cv.sc[1] = l1; cv.sc[2] = cf;
             }
         }
         // rotate into the Ritz basis, residuals, the power step and its Gram-Schmidt sums in one round
@@ -303,11 +345,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         const float2 p1 = make_float2(ny1.x - cf * nx1.x, ny1.y - cf * nx1.y);
         float n0 = p0.x * p0.x + p0.y * p0.y, n1 = p1.x * p1.x + p1.y * p1.y;
         float pr = p0.x * p1.x + p0.y * p1.y, pi = p0.x * p1.y - p0.y * p1.x;   // conj(p0) p1
-        {
-            float z2 = 0.f, z3 = 0.f;
-            sf_block_sum4(r0s, r1s, z2, z3, cv.red);
-            sf_block_sum4(n0, n1, pr, pi, cv.red);
-        }
+        sf_block_sum8(r0s, r1s, n0, n1, pr, pi, cv.red);
         res0 = sqrtf(r0s);
         res1 = sqrtf(r1s);
         if (it + 1 < iters) {
@@ -328,6 +366,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             cv.X1[tid] = tid < n ? nx1 : make_float2(0.f, 0.f);
         }
         __syncthreads();
+        mark(2);
     }
     const float mu0 = l0 - cf, mu1 = l1 - cf;
 
@@ -335,7 +374,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
     int tI[TPW], tJ[TPW];
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
-        const int t = wave + SF_WAVES * s;
+        const int t = wave * TPW + s;
         int I = 0;
         while ((I + 1) * (I + 2) / 2 <= t) ++I;
         tI[s] = I;
@@ -362,6 +401,10 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
     for (int K = 0; K < nslab; ++K) {
         const int k0 = 32 * K;
         __syncthreads();   // the previous slab's readers are done
+        // (opaque copy of the thread index: everything derived from it is recomputed per slab instead of being hoisted out of
+        //  the loop and spilled -- a reload from scratch is a memory round trip)
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
         // element pair (j; k, k + 1) of E^T: e_q = E[k + q][j].  j <= k: from rows k, k + 1 of Z (lanes over j);
         // j >= k + 1: conj of E[j][k + q] from row j of Z (lanes over k)
         auto deflate = [&](float2 a, int row, int col) {   // E[row][col] from A[row][col] (row >= col)
@@ -375,21 +418,35 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             }
             return a;
         };
-#pragma unroll 2
-        for (int q = 0; q < 8; ++q) {   // L region: two row pairs per sweep, 256 columns each
-            const int kp = 2 * q + (tid >> 8), j = tid & 255;
-            const int k = k0 + 2 * kp;
-            if (j <= k && j < n) {
-                float2 e0 = make_float2(0.f, 0.f), e1 = e0;
-                if (k < n) e0 = deflate(sf_a_elem(k, j, D, Z[(int64_t)k * n + j], ir, corner, cv.hh[k], cv.ph[j]), k, j);
-                if (k + 1 < n)
-                    e1 = deflate(sf_a_elem(k + 1, j, D, Z[(int64_t)(k + 1) * n + j], ir, corner, cv.hh[k + 1], cv.ph[j]), k + 1, j);
-                ETre32[j * P32 + kp] = sf_pack_bf16(e0.x, e1.x);
-                ETim32[j * P32 + kp] = sf_pack_bf16(e0.y, e1.y);
+        {   // L region: three row pairs per sweep, 256 columns each; the loads of three sweeps in flight together
+            constexpr int RP = SF_THREADS / 256, LQ = (16 + RP - 1) / RP, LB = 3;
+#pragma unroll
+            for (int qb = 0; qb < LQ; qb += LB) {
+                float2 zl0[LB], zl1[LB];
+#pragma unroll
+                for (int u = 0; u < LB; ++u) {
+                    const int kp = RP * (qb + u) + (tl >> 8), j = tl & 255;
+                    const int k = k0 + 2 * kp;
+                    const bool v = kp < 16 && j <= k && j < n;
+                    zl0[u] = (v && k < n) ? Z[(int64_t)k * n + j] : make_float2(0.f, 0.f);
+                    zl1[u] = (v && k + 1 < n) ? Z[(int64_t)(k + 1) * n + j] : make_float2(0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < LB; ++u) {
+                    const int kp = RP * (qb + u) + (tl >> 8), j = tl & 255;
+                    const int k = k0 + 2 * kp;
+                    if (kp < 16 && j <= k && j < n) {
+                        float2 e0 = make_float2(0.f, 0.f), e1 = e0;
+                        if (k < n) e0 = deflate(sf_a_elem(k, j, D, zl0[u], ir, corner, cv.hh[k], cv.ph[j]), k, j);
+                        if (k + 1 < n) e1 = deflate(sf_a_elem(k + 1, j, D, zl1[u], ir, corner, cv.hh[k + 1], cv.ph[j]), k + 1, j);
+                        ETre32[j * P32 + kp] = sf_pack_bf16(e0.x, e1.x);
+                        ETim32[j * P32 + kp] = sf_pack_bf16(e0.y, e1.y);
+                    }
+                }
             }
         }
-        if (tid < 16 && D >= 256) {   // (the L sweep covers j <= 255: the corner element j = k = D = 256 of the last slab)
-            const int kp = tid, k = k0 + 2 * kp, j = 256;
+        if (tl < 16 && D >= 256) {   // (the L sweep covers j <= 255: the corner element j = k = D = 256 of the last slab)
+            const int kp = tl, k = k0 + 2 * kp, j = 256;
             if (j <= k && j < n) {   // (k = 256: the corner; k > 256: padding of the k dimension)
                 float2 e0 = make_float2(0.f, 0.f);
                 if (k < n) e0 = deflate(sf_a_elem(k, j, D, Z[(int64_t)k * n + j], ir, corner, cv.hh[k], cv.ph[j]), k, j);
@@ -397,34 +454,50 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
                 ETim32[j * P32 + kp] = sf_pack_bf16(e0.y, 0.f);
             }
         }
-        for (int jb = k0 + 1; jb < n; jb += 32) {   // U region: 32 rows of Z per sweep, 16 lanes per row
-            const int j = jb + (tid >> 4), kp = tid & 15;
-            const int k = k0 + 2 * kp;
-            if (j < n && j >= k + 1) {
-                const float hj = cv.hh[j];
-                const float2 z0 = Z[(int64_t)j * n + k];
-                float2 e0 = deflate(sf_a_elem(j, k, D, z0, ir, corner, hj, cv.ph[k]), j, k), e1 = make_float2(0.f, 0.f);
-                if (k + 1 < n) {   // (k + 1 <= j; equal: the diagonal element)
-                    const float2 z1 = Z[(int64_t)j * n + k + 1];
-                    e1 = deflate(sf_a_elem(j, k + 1, D, z1, ir, corner, hj, cv.ph[k + 1]), j, k + 1);
+        {   // U region: 48 rows of Z per sweep (16 lanes per row), two sweeps' loads in flight
+            constexpr int RPS = SF_THREADS / 16;
+            const int kp = tl & 15, k = k0 + 2 * kp;
+            for (int jb = k0 + 1; jb < n; jb += 2 * RPS) {
+                float2 zu0[2], zu1[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int j = jb + RPS * u + (tl >> 4);
+                    const bool v = j < n && j >= k + 1;
+                    zu0[u] = v ? Z[(int64_t)j * n + k] : make_float2(0.f, 0.f);
+                    zu1[u] = (v && k + 1 < n) ? Z[(int64_t)j * n + k + 1] : make_float2(0.f, 0.f);
                 }
-                ETre32[j * P32 + kp] = sf_pack_bf16(e0.x, e1.x);     // E[k][j] = conj(E[j][k])
-                ETim32[j * P32 + kp] = sf_pack_bf16(-e0.y, -e1.y);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int j = jb + RPS * u + (tl >> 4);
+                    if (j < n && j >= k + 1) {
+                        const float hj = cv.hh[j];
+                        float2 e0 = deflate(sf_a_elem(j, k, D, zu0[u], ir, corner, hj, cv.ph[k]), j, k), e1 = make_float2(0.f, 0.f);
+                        if (k + 1 < n)   // (k + 1 <= j; equal: the diagonal element)
+                            e1 = deflate(sf_a_elem(j, k + 1, D, zu1[u], ir, corner, hj, cv.ph[k + 1]), j, k + 1);
+                        ETre32[j * P32 + kp] = sf_pack_bf16(e0.x, e1.x);     // E[k][j] = conj(E[j][k])
+                        ETim32[j * P32 + kp] = sf_pack_bf16(-e0.y, -e1.y);
+                    }
+                }
             }
         }
         __syncthreads();
+        mark(3);
         // matrix cores: O_IJ += sum_k conj(E[k][i]) E[k][j]
         {
-            const int r32 = lane & 31, kh = lane >> 5;
+            int r32 = lane & 31, kh = lane >> 5;
+            asm volatile("" : "+v"(r32), "+v"(kh));   // (see above: no hoisted, spilled operand addresses)
 #pragma unroll
-            for (int s = 0; s < TPW; ++s) {
-                if (wave + SF_WAVES * s < ntri) {   // (wave-uniform)
-                    const int ia = 32 * tI[s] + r32, jb_ = 32 * tJ[s] + r32;
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = 8 * ks + 4 * kh;   // dwords: 16 k-values per step, 8 per lane half
+                uint4 are = make_uint4(0, 0, 0, 0), aim = are;
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const int off = 8 * ks + 4 * kh;   // dwords: 16 k-values per step, 8 per lane half
-                        const uint4 are = *reinterpret_cast<const uint4 *>(ETre32 + ia * P32 + off);
-                        const uint4 aim = *reinterpret_cast<const uint4 *>(ETim32 + ia * P32 + off);
+                for (int s = 0; s < TPW; ++s) {
+                    if (wave * TPW + s < ntri) {   // (wave-uniform)
+                        const int ia = 32 * tI[s] + r32, jb_ = 32 * tJ[s] + r32;
+                        if (s == 0 || tI[s] != tI[s - 1]) {   // (uniform) consecutive tiles share the row operand
+                            are = *reinterpret_cast<const uint4 *>(ETre32 + ia * P32 + off);
+                            aim = *reinterpret_cast<const uint4 *>(ETim32 + ia * P32 + off);
+                        }
                         const uint4 bre = *reinterpret_cast<const uint4 *>(ETre32 + jb_ * P32 + off);
                         const uint4 bim = *reinterpret_cast<const uint4 *>(ETim32 + jb_ * P32 + off);
                         const uint4 nbre = make_uint4(bre.x ^ 0x80008000u, bre.y ^ 0x80008000u, bre.z ^ 0x80008000u,
@@ -441,6 +514,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
                 }
             }
         }
+        mark(4);
         // border row of E^2 on the vector ALUs
         if (tid < n) {
             const unsigned *dre = ETre32 + D * P32, *dim = ETim32 + D * P32;
@@ -454,6 +528,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
                 ob.y += ar0 * bi0 - ai0 * br0 + ar1 * bi1 - ai1 * br1;
             }
         }
+        mark(5);
     }
     __syncthreads();
     if (tid < NP) cv.Ob[tid] = tid < n ? ob : make_float2(0.f, 0.f);
@@ -464,7 +539,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         const int r32 = lane & 31, kh = lane >> 5;
 #pragma unroll
         for (int s = 0; s < TPW; ++s) {
-            if (wave + SF_WAVES * s < ntri) {
+            if (wave * TPW + s < ntri) {
                 const float wgt = tI[s] == tJ[s] ? 1.f : 2.f;   // a diagonal tile holds both triangles
                 const int gj = 32 * tJ[s] + r32;
 #pragma unroll
@@ -528,6 +603,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         }
     }
     __syncthreads();
+    mark(6);
     if (cv.flags[0]) return;   // (uniform) the eigen-pipeline takes this matrix
 
     // ---- G from the accumulator layout ---------------------------------------------------------------------------------------
@@ -539,27 +615,36 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         const int r32 = lane & 31, kh = lane >> 5;
 #pragma unroll
         for (int s = 0; s < TPW; ++s) {
-            if (wave + SF_WAVES * s < ntri) {
+            if (wave * TPW + s < ntri) {
                 const int gj = 32 * tJ[s] + r32;
                 const float2 vj0 = cv.X0[gj < n ? gj : 0], vj1 = cv.X1[gj < n ? gj : 0];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int gi = 32 * tI[s] + (q & 3) + 8 * (q >> 2) + 4 * kh;
-                    if (gi < D && gj <= gi) {
-                        const float hi = cv.hh[gi];
-                        const float2 a = sf_a_elem(gi, gj, D, Z[(int64_t)gi * n + gj], ir, corner, hi, make_float2(0.f, 0.f));
-                        const float2 p0 = cmulc(cv.X0[gi], vj0), p1 = cmulc(cv.X1[gi], vj1);
-                        float2 g = make_float2(a1f * a.x + a2f * accRe[s][q] + g0f * p0.x + g1f * p1.x,
-                                               a1f * a.y + a2f * accIm[s][q] + g0f * p0.y + g1f * p1.y);
-                        float cz = 0.f;
-                        if (gi == gj) {
-                            g.x += k0c;
-                            g.y = 0.f;
-                            cz = hi;
+                for (int qb = 0; qb < 16; qb += 8) {
+                    float2 zq[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {   // (the loads of half a tile first)
+                        const int q = qb + u, gi = 32 * tI[s] + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                        zq[u] = (gi < D && gj <= gi) ? Z[(int64_t)gi * n + gj] : make_float2(0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int q = qb + u, gi = 32 * tI[s] + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                        if (gi < D && gj <= gi) {
+                            const float hi = cv.hh[gi];
+                            const float2 a = sf_a_elem(gi, gj, D, zq[u], ir, corner, hi, make_float2(0.f, 0.f));
+                            const float2 p0 = cmulc(cv.X0[gi], vj0), p1 = cmulc(cv.X1[gi], vj1);
+                            float2 g = make_float2(a1f * a.x + a2f * accRe[s][q] + g0f * p0.x + g1f * p1.x,
+                                                   a1f * a.y + a2f * accIm[s][q] + g0f * p0.y + g1f * p1.y);
+                            float cz = 0.f;
+                            if (gi == gj) {
+                                g.x += k0c;
+                                g.y = 0.f;
+                                cz = hi;
+                            }
+                            Gb[(int64_t)gi * n + gj] = g;
+                            const float dr = g.x - cz;
+                            acc += (gi == gj ? 1.f : 2.f) * (dr * dr + g.y * g.y);
                         }
-                        Gb[(int64_t)gi * n + gj] = g;
-                        const float dr = g.x - cz;
-                        acc += (gi == gj ? 1.f : 2.f) * (dr * dr + g.y * g.y);
                     }
                 }
             }
@@ -586,6 +671,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         sf_block_sum4(acc, z1, z2, z3, cv.red);
     }
     if (tid == 0) rn[b] = sqrtf(acc);
+    mark(7);
 }
 
 bool use_spectral_fused() {
@@ -599,9 +685,25 @@ static int sf_launch(int D, int64_t nb, const float *lw, const float2 *phi, cons
     const size_t lds = SfCarve::bytes(D + 1);
     ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_fused_kernel<TPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
+    static const bool timing = getenv("ADMMNET_SF_TIMING") != nullptr;   // developer aid, never on by default
+    unsigned long long *ptime = nullptr;
+    if (timing) {
+        ADMM_HIP(hipMalloc(&ptime, 16 * sizeof(unsigned long long)));
+        ADMM_HIP(hipMemsetAsync(ptime, 0, 16 * sizeof(unsigned long long), st));
+    }
     hipLaunchKernelGGL((sp_fused_kernel<TPW>), dim3((unsigned)nb), dim3(SF_THREADS), lds, st, D, lw, phi, h, Z, G, rn, flag, status,
-                       tol, iters);
+                       tol, iters, ptime);
     ADMM_HIP(hipGetLastError());
+    if (timing) {
+        unsigned long long hb[16];
+        ADMM_HIP(hipMemcpyAsync(hb, ptime, sizeof(hb), hipMemcpyDeviceToHost, st));
+        ADMM_HIP(hipStreamSynchronize(st));
+        ADMM_HIP(hipFree(ptime));
+        fprintf(stderr, "[sf timing D=%d nb=%lld] cycles per workgroup: setup %.0f | matvec %.0f ritz %.0f (all passes) | stage %.0f "
+                "mfma %.0f border %.0f (all slabs) | model %.0f | assemble %.0f\n", D, (long long)nb, hb[0] / (double)nb,
+                hb[1] / (double)nb, hb[2] / (double)nb, (hb[3]) / (double)nb, hb[4] / (double)nb, hb[5] / (double)nb,
+                hb[6] / (double)nb, hb[7] / (double)nb);
+    }
     return ADMMNET_OK;
 }
 
@@ -616,9 +718,7 @@ int launch_spectral_fused(int D, int64_t nb, const float *lw, const float2 *phi,
     switch (tpw) {
         case 1: return sf_launch<1>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, st);
         case 2: return sf_launch<2>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, st);
-        case 3: return sf_launch<3>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, st);
-        case 4: return sf_launch<4>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, st);
-        default: return sf_launch<5>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, st);
+        default: return sf_launch<3>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, st);
     }
 }
 
