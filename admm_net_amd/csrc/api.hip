@@ -515,7 +515,7 @@ int admmnet_layer_front(const admmnet_cfg *cfg, const float *W, int32_t k, const
         if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, wc, false, sc, false, lean))) return rc;
         const bool fused = fuse_back(D, wc);
         Ws wf = wc;
-        if (use_spectral() && wc.spec_flag && lean && (D > 128 || fused)) {
+        if (use_spectral() && wc.spec_flag && lean && D >= 8 && (D > 128 || fused)) {
             // opt-in: G as a matrix function where the spectrum allows it (checked per matrix); the kernels below then only
             // run the matrices it flagged
             if ((rc = launch_spectral(D, nb, lw, phk, hk, ws.Z + b0 * n * n, Gk, ws.rn + b0, wc, status, sc, true))) return rc;
