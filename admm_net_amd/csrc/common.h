@@ -204,7 +204,7 @@ int launch_synth(int64_t B, int Nb, int Nd, int L, unsigned long long seed, doub
                  float2 *phi_label, hipStream_t st);
 
 // ---- optional per-kernel-class HIP-event profiler (bench.py roofline leg) ------
-enum KernelClass { KC_PREP = 0, KC_TRIDIAG, KC_TQL, KC_ROTAPPLY, KC_REBUILD, KC_ZSTEP, KC_HEAD, KC_SPECTRUM, KC_COUNT };
+enum KernelClass { KC_PREP = 0, KC_TRIDIAG, KC_TQL, KC_ROTAPPLY, KC_REBUILD, KC_ZSTEP, KC_HEAD, KC_SPECTRUM, KC_GFUNC, KC_COUNT };
 struct ProfScope {   // records start/stop events on `st` around a launcher body when profiling is on
     int slot;
     hipStream_t st;

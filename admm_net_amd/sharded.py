@@ -122,6 +122,9 @@ class ShardedForward:
                 dist.all_reduce(sc, op=dist.ReduceOp.SUM, group=self.group)
             eng.back(k, sc[0] / sc[1])
         phi, head = eng.finish()
+        # status words of the C ABI after the forward: [0] eigensolver failures, [1] matrix-layers the matrix-function route
+        # handed to the eigensolver, [2] matrix-layers it evaluated itself, [3] of [1] those rejected by the model of f
+        self.last_status = [int(v) for v in eng.status.tolist()] if hasattr(eng, "status") else [0, 0, 0, 0]
         if gather and world > 1:
             phi = self._gather(phi, dim=0)
             if head is not None:

@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0                  # the same guide: HBM3E, ~8 TB/s
 WORKLOADS = {
     # name: (Nb, Nd, K, batch per GPU, tau atoms, f atoms)   -- BASELINE.json configs[1] / [2] / [4], SURVEY section 0
     "cfg2": (8, 16, 8, 4096, 32, 16),
@@ -46,7 +47,9 @@ WORKLOADS = {
 }
 # kernel classes of admmnet_profile_read (include/admmnet.h): "trideig" = tridiagonal eigensolver
 # (divide & conquer, or QL with ADMMNET_EIG=ql), "backtransform" = V = Q W (MFMA GEMM, or rotation replay)
-KERNELS = ["prep", "tridiag", "trideig", "backtransform", "rebuild", "zstep", "head", "spectrum"]
+# "gfunction" = the G-layer evaluated as a matrix function (csrc/spectral_fused.hip: the default route; the four eigen-classes
+# then only see the matrices its per-matrix checks send back)
+KERNELS = ["prep", "tridiag", "trideig", "backtransform", "rebuild", "zstep", "head", "spectrum", "gfunction"]
 
 
 def flops_per_signal(K, n, D, natoms):
@@ -202,9 +205,10 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     log(f"timed {args.steps} steps: {dt:.3f} s")
-    ms = (ctypes.c_double * 8)()
-    cnt = (ctypes.c_int64 * 8)()
-    _lib.check(lib.admmnet_profile_read(ms, cnt, 8), "admmnet_profile_read")
+    NK = len(KERNELS)
+    ms = (ctypes.c_double * NK)()
+    cnt = (ctypes.c_int64 * NK)()
+    _lib.check(lib.admmnet_profile_read(ms, cnt, NK), "admmnet_profile_read")
     dropped = int(lib.admmnet_profile_dropped())      # launches the event pool could not record (0 in a healthy run)
     lib.admmnet_profile_enable(0)
     if dropped:
@@ -224,15 +228,20 @@ def main():
         signals = B * world * args.steps
         value = signals / dt
         F = flops_per_signal(K, n, D, natoms)
-        per = {KERNELS[i]: (ms[i], cnt[i]) for i in range(8)}
-        dom = max(("tridiag", "trideig", "backtransform", "rebuild"), key=lambda k_: per[k_][0])
-        kf = kernel_flops_per_matrix(n)[dom]
+        per = {KERNELS[i]: (ms[i], cnt[i]) for i in range(NK)}
+        dom = max(("tridiag", "trideig", "backtransform", "rebuild", "gfunction"), key=lambda k_: per[k_][0])
+        fast = dom == "gfunction"
+        kf = 0.0 if fast else kernel_flops_per_matrix(n)[dom]
         chunk = min(B, 8192)
         launches = max(per[dom][1], 1)
         avg_ms = per[dom][0] / launches
-        mats_per_launch = B / math.ceil(B / chunk)          # every launch of an eigen-kernel works on one chunk
+        mats_per_launch = B / math.ceil(B / chunk)          # every launch of a G-layer kernel works on one chunk
         ach = kf * mats_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic, mfma_busy = measured_counters(args.workload, dom, mats_per_launch)
+        # how the G-layers of the last timed step were evaluated (status words of the C ABI: [1] matrix-layers the per-matrix
+        # checks sent to the eigensolver, [2] matrix-layers evaluated as a matrix function)
+        st_words = [int(v) for v in getattr(sf, "last_status", [0, 0, 0, 0])]
+        glayers = st_words[1] + st_words[2]
         # time-weighted matrix-core occupancy over ALL kernel classes: this run's HIP-event time per class x the
         # MFMA-busy fraction of that class from the committed SQ pass (classes without matrix-core work count as 0)
         tot_ms = sum(v[0] for v in per.values())
@@ -241,7 +250,30 @@ def main():
         mfma_w = (round(sum(per[k_][0] * busy[k_] for k_ in known) / tot_ms, 4)
                   if tot_ms > 0 and len(known) == 4 else None)
         kms = None if dropped else {k_: round(v[0] / args.steps, 3) for k_, v in per.items()}
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+        if fast:
+            # the dominant kernel streams the lower triangles: ALGORITHMIC bytes per matrix-layer = Z in + G out, 8 n (n + 1) B
+            # (DESIGN.md section 4); what it really moves is `traffic` (PMC), several sweeps of Z through the L2 / MALL
+            gbytes = 8.0 * n * (n + 1)
+            ach_gbs = gbytes * mats_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": "gfunction (sp_fused_kernel)", "achieved": round(ach_gbs, 2), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(ach_gbs / PEAK_HBM_GBS, 5), "traffic": traffic, "mfma_busy": mfma_busy,
+                    "avg_launch_ms": round(avg_ms, 4), "matrices_per_launch": mats_per_launch,
+                    "algorithmic_bytes_per_matrix": gbytes,
+                    "eigensolver_equivalent_tflops": round(F * value / world / 1e12, 3),
+                    "eigensolver_equivalent_note": (
+                        "value x the CANONICAL flop count of SURVEY 8(d) (24 n^3 per matrix-layer through an eigensolver): what an "
+                        "eigensolver pipeline would have to sustain for this throughput -- NOT executed work and not a utilisation "
+                        "(it exceeds the fp32 matrix-core peak of %.1f TFLOP/s): the G-layer is evaluated as a matrix function "
+                        "(two-vector subspace iteration + one Hermitian square in bf16 on the matrix cores, checked per matrix; "
+                        "csrc/spectral.hip) and only the matrices its checks reject run the eigensolver.  ADMMNET_SPECTRAL=0 "
+                        "measures the eigensolver pipeline itself (profiles/, README)." % PEAK_FP32_MFMA_TFLOPS),
+                    "glayer_matrix_function_fraction": (round(st_words[2] / glayers, 5) if glayers else None),
+                    "glayer_eigensolver_fallback_fraction": (round(st_words[1] / glayers, 5) if glayers else None),
+                    "kernel_ms_per_step": None if dropped else {k_: round(v[0] / args.steps, 3) for k_, v in per.items()},
+                    "kernel_ms_sum_over_ms_per_step": (None if dropped else round(
+                        sum(v[0] for v in per.values()) / args.steps / (dt / args.steps * 1e3), 4)),
+                    "profile_dropped_launches": dropped}
+        roof_eig = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 5),
                 "traffic": traffic, "mfma_busy": mfma_busy,
                 "avg_launch_ms": round(avg_ms, 4), "matrices_per_launch": mats_per_launch,
@@ -261,6 +293,8 @@ def main():
                 "kernel_ms_sum_over_ms_per_step": (None if dropped else
                                                    round(tot_ms / args.steps / (dt / args.steps * 1e3), 4)),
                 "profile_dropped_launches": dropped}
+        if not fast:
+            roof = roof_eig
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(model, Nb, Nd, K, y, b, s, out[0], args.workload, head=not post_search)
@@ -279,7 +313,9 @@ def main():
                                         f"batch {B}/GPU + spectrum on {natoms} atoms"),
                            "batch_per_gpu": B, "global_batch": B * world, "K": K, "D": D, "n": n,
                            "natoms": natoms, "batch_mean_scope": "global", "chunk": chunk,
-                           "weights": "torch.manual_seed(0) default init"},
+                           "weights": "torch.manual_seed(0) default init",
+                           "glayer": ("eigensolver pipeline (ADMMNET_SPECTRAL=0)" if os.environ.get("ADMMNET_SPECTRAL") == "0"
+                                      else "matrix function, checked per matrix; eigensolver on the rejected matrices")},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -211,11 +211,11 @@ int admmnet_synth_batch(int64_t B, int32_t Nb, int32_t Nd, int32_t L, uint64_t s
  * caller's stream.  admmnet_profile_read synchronises those events, returns the
  * summed milliseconds and launch counts per kernel class and clears the buffer.
  * Classes: 0 prep, 1 tridiag, 2 tridiagonal eigensolver, 3 back-transform (V = Q W),
- * 4 rebuild, 5 zstep, 6 head, 7 spectrum (ADMMNET_KERNEL_CLASSES entries).
+ * 4 rebuild, 5 zstep, 6 head, 7 spectrum, 8 G-layer as a matrix function (ADMMNET_KERNEL_CLASSES entries).
  * The event pool grows with the number of launches between two reads; a launch is only left out when an event
  * cannot be created, and admmnet_profile_dropped() returns how many were (0 in any healthy run; bench.py refuses
  * to print per-step sums otherwise).  Guarded by one mutex; off by default. */
-#define ADMMNET_KERNEL_CLASSES 8
+#define ADMMNET_KERNEL_CLASSES 9
 int admmnet_profile_enable(int32_t on);
 int admmnet_profile_read(double *ms_total, int64_t *launches, int32_t nclasses);
 int64_t admmnet_profile_dropped(void);

@@ -35,22 +35,31 @@ for name in ("phiest_8x16_K3_perturbed", "admmnet_10x10_K3_default", "phiest_16x
 print("RESULT " + json.dumps(out))
 """
 
+# The forward's default G-layer route is the matrix function of csrc/spectral_fused.hip, which leaves the eigensolver pipeline only
+# the matrices it rejects: the A/B switches of that pipeline are therefore tested with ADMMNET_SPECTRAL=0 (every matrix through
+# the eigensolver), and the matrix-function route has variants of its own.
+EIGEN = {"ADMMNET_SPECTRAL": "0"}
 VARIANTS = {
-    "eig_ql": {"ADMMNET_EIG": "ql"},
-    "no_arrow": {"ADMMNET_ARROW": "0"},
-    "unfused_back": {"ADMMNET_FUSE_BACK": "0", "ADMMNET_ARROW": "0"},
-    "tridiag_lds": {"ADMMNET_TRIDIAG": "lds", "ADMMNET_ARROW": "0"},
-    "full_storage": {"ADMMNET_LEAN": "0"},
+    "eigen_only": dict(EIGEN),
+    "eig_ql": dict(EIGEN, ADMMNET_EIG="ql"),
+    "no_arrow": dict(EIGEN, ADMMNET_ARROW="0"),
+    "unfused_back": dict(EIGEN, ADMMNET_FUSE_BACK="0", ADMMNET_ARROW="0"),
+    "tridiag_lds": dict(EIGEN, ADMMNET_TRIDIAG="lds", ADMMNET_ARROW="0"),
+    "full_storage": dict(EIGEN, ADMMNET_LEAN="0"),
     # 128 < D <= 256: per-reflector register sweep + explicit Q + Q W; D = 192 runs at its own size instead of padded to 256
-    "sweep_big": {"ADMMNET_TRIDIAG_BIG": "sweep"},
-    "explicit_q": {"ADMMNET_BACK": "q"},               # D = 256: panel tridiagonalisation, explicit Q + Q W
-    "panel_one_stage": {"ADMMNET_PN_SPLIT": "0"},      # D = 256: the whole panel reduction in the 8-wave kernel
-    "panel_two_stages": {"ADMMNET_PN_SPLIT": "8"},     # D = 256: panels 0..7 | 8..15 (default: 0..7 | 8..11 | 12..15)
-    "two_streams": {"ADMMNET_STREAMS": "2", "ADMMNET_TEST_CHUNK": "1"},   # two chunks in flight (B = 2 .. 3 at chunk = 1)
-    "dc_poison": {"ADMMNET_DC_POISON": "1"},           # D&C ping-pong buffers start as NaN instead of whatever they hold
-    # the G-layer as a matrix function wherever the per-matrix checks allow it, the eigensolver on the rest (spectral.hip)
-    "spectral": {"ADMMNET_SPECTRAL": "1"},
-    "spectral_two_streams": {"ADMMNET_SPECTRAL": "1", "ADMMNET_STREAMS": "2", "ADMMNET_TEST_CHUNK": "1"},
+    "sweep_big": dict(EIGEN, ADMMNET_TRIDIAG_BIG="sweep"),
+    "explicit_q": dict(EIGEN, ADMMNET_BACK="q"),               # D = 256: panel tridiagonalisation, explicit Q + Q W
+    "panel_one_stage": dict(EIGEN, ADMMNET_PN_SPLIT="0"),      # D = 256: the whole panel reduction in the 8-wave kernel
+    "panel_two_stages": dict(EIGEN, ADMMNET_PN_SPLIT="8"),     # D = 256: panels 0..7 | 8..15 (default: 0..7 | 8..11 | 12..15)
+    "two_streams": dict(EIGEN, ADMMNET_STREAMS="2", ADMMNET_TEST_CHUNK="1"),   # two chunks in flight (B = 2 .. 3 at chunk = 1)
+    "dc_poison": dict(EIGEN, ADMMNET_DC_POISON="1"),           # D&C ping-pong buffers start as NaN instead of whatever they hold
+    # the matrix-function route (default): several chunks on two streams; its multi-kernel form; every matrix rejected by the
+    # model check (tolerance 0), i.e. the flag / skip machinery carrying the whole batch; full storage turns the route off
+    "spectral_two_streams": {"ADMMNET_STREAMS": "2", "ADMMNET_TEST_CHUNK": "1"},
+    "spectral_chunks": {"ADMMNET_TEST_CHUNK": "1"},
+    "spectral_unfused": {"ADMMNET_SPECTRAL_FUSED": "0"},
+    "spectral_all_rejected": {"ADMMNET_SPECTRAL_TOL": "0"},
+    "spectral_one_pass_cap": {"ADMMNET_SPECTRAL_ITERS": "1"},   # (one subspace pass cannot pass the residual check either)
 }
 
 
