@@ -512,14 +512,17 @@ int admmnet_layer_front(const admmnet_cfg *cfg, const float *W, int32_t k, const
             if ((rc = launch_arrow_rebuild(D, nb, lw, phk, hk, Gk, ws.rn + b0, nullptr, status, wc, sc, lean))) return rc;
             continue;
         }
-        if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, wc, false, sc, false, lean))) return rc;
         const bool fused = fuse_back(D, wc);
+        // G as a matrix function where the spectrum allows it (checked per matrix, spectral.hip); the eigen-pipeline below then
+        // only runs the matrices it flagged
+        const bool spec = use_spectral() && wc.spec_flag && lean && D >= 8 && (D > 128 || fused);
+        const bool late_image = spec && D > 128 && use_spectral_fused();   // (the image only for the flagged matrices, afterwards)
+        if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, wc, false, sc, false, lean, late_image))) return rc;
         Ws wf = wc;
-        if (use_spectral() && wc.spec_flag && lean && D >= 8 && (D > 128 || fused)) {
-            // opt-in: G as a matrix function where the spectrum allows it (checked per matrix); the kernels below then only
-            // run the matrices it flagged
+        if (spec) {
             if ((rc = launch_spectral(D, nb, lw, phk, hk, ws.Z + b0 * n * n, Gk, ws.rn + b0, wc, status, sc, true))) return rc;
             wf.skip = wc.spec_flag;
+            if (late_image && (rc = launch_half_image(D, nb, lw, phk, hk, ws.Z + b0 * n * n, wf, sc))) return rc;
         }
         // (D <= 128: the tridiagonalisation's own loader forms A from the lower triangle of Z; D = 256 reads the half image)
         if ((rc = eig_chunk(D, nb, wf, status, sc, !fused, (lean && D <= 128) ? ws.Z + b0 * n * n : nullptr, phk, hk, lw)))

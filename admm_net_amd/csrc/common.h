@@ -123,7 +123,11 @@ int64_t pick_chunk(const admmnet_cfg *cfg, int64_t B);
 // prep.hip
 int launch_prep(const admmnet_cfg *cfg, const float *lw, int k, const float2 *y, const float2 *b,
                 const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st,
-                bool no_matrix = false, bool lean = false);
+                bool no_matrix = false, bool lean = false, bool no_image = false);
+// (no_image, D > 128 lean route: only the Z update streams; launch_half_image then builds the image of the matrices with
+//  ws.skip[s] != 0 from the updated Z)
+int launch_half_image(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, const float2 *Z, const Ws &ws,
+                      hipStream_t st);
 // (image builders: the matrix lands in an eig_dim x eig_dim image, zero outside its own D x D block)
 int launch_build_generic(int n, int64_t nb, const float2 *A, const Ws &ws, hipStream_t st);
 int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const float2 *phi, const float *h,

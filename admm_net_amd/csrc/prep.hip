@@ -48,6 +48,8 @@ constexpr int PM_PHI_ONLY = 4;   // last layer: only phi is needed (admm_net.py:
 constexpr int PM_NO_MATRIX = 8;  // layer 0 on the arrowhead path (arrow.hip): phi and h only, A is never formed
 constexpr int PM_HALF = 32;      // D = 256 (tridiag_panel.hip): G / Z streamed as lower triangles, the image written for the lower
                                  // 16-block triangle only (diagonal blocks in full) -- the tiles that kernel loads
+constexpr int PM_NOIMG = 64;     // with PM_HALF: only the lazy Z update streams, no image -- the G-layer is evaluated as a matrix function
+                                 // straight from Z (spectral_fused.hip); the matrices it rejects get their image from half_image_kernel
 constexpr int PM_LEAN = 16;      // G / Z kept as lower triangles, A built by the tridiagonalisation's own loader
                                  // (tridiag_reg.hip): only the lazy Z update streams here, 24 n^2 / 2 bytes per signal
 
@@ -62,6 +64,60 @@ __device__ __forceinline__ void pad_image(float2 *Mg, int D, int Dimg, int tid, 
         if (i >= D || j >= D) Mg[t] = zero2;
     }
     for (int j = D + tid; j < Dimg; j += nthreads) Mg[(int64_t)Dimg * Dimg + j] = zero2;
+}
+
+// One element (i >= j) of the half image of A = C_g - Z / rho from the state element zn = Z[i][j]: the lower 16-block triangle, diagonal
+// blocks in full, the arrow column as the conjugate of the arrow row (what tridiag_panel_kernel loads).
+__device__ __forceinline__ void half_image_store(float2 *Mg, int D, int Dimg, int i, int j, float2 zn, float corner_g,
+                                                 float inv_rho_g, float2 phj, float hi) {
+    if (i == D) {
+        if (j == D) Mg[(int64_t)Dimg * Dimg + Dimg] = make_float2(corner_g - inv_rho_g * zn.x, -inv_rho_g * zn.y);
+        else Mg[(int64_t)Dimg * Dimg + j] = make_float2(phj.x - inv_rho_g * zn.x, phj.y + inv_rho_g * zn.y);   // A[j][D] = conj(A[D][j])
+    } else {
+        const float2 a = make_float2((i == j ? hi : 0.f) - inv_rho_g * zn.x, -inv_rho_g * zn.y);
+        Mg[(int64_t)i * Dimg + j] = a;
+        if (i != j && (i >> 4) == (j >> 4)) Mg[(int64_t)j * Dimg + i] = make_float2(a.x, -a.y);
+    }
+}
+// The zero padding of the half image on the padded route (Dimg > D): rows D .. Dimg - 1 of the lower 16-block triangle (whole
+// diagonal blocks: the block that holds row D also gets its columns >= D), the arrow entries behind D.
+__device__ __forceinline__ void half_image_pad(float2 *Mg, int D, int Dimg, int tid, int nthreads) {
+    const float2 zero2 = make_float2(0.f, 0.f);
+    const int pad = Dimg - D;
+    for (int t = tid; t < pad * Dimg; t += nthreads) {
+        const int i = D + t / Dimg, j = t - (i - D) * Dimg;
+        if ((j >> 4) <= (i >> 4)) Mg[(int64_t)i * Dimg + j] = zero2;
+    }
+    const int i0 = D & ~15;                      // rows of the block that holds row D, above it
+    for (int t = tid; t < (D - i0) * 16; t += nthreads) {
+        const int i = i0 + (t >> 4), j = i0 + (t & 15);
+        if (j >= D) Mg[(int64_t)i * Dimg + j] = zero2;
+    }
+    for (int j = D + tid; j < Dimg; j += nthreads) Mg[(int64_t)Dimg * Dimg + j] = zero2;
+}
+
+// The half image for the matrices the matrix-function route hands to the eigensolver (skip[s] != 0), from the already updated Z.
+__global__ __launch_bounds__(PR_THREADS) void half_image_kernel(int D, int Dimg, const float *__restrict__ lw,
+                                                                const float2 *__restrict__ phi, const float *__restrict__ h,
+                                                                const float2 *__restrict__ Z, float2 *__restrict__ Mbuf,
+                                                                const int *__restrict__ skip) {
+    const int64_t s = blockIdx.x;
+    if (skip && skip[s] == 0) return;
+    const int n = D + 1, tid = threadIdx.x;
+    const float corner_g = lw[S_CORNER_G], inv_rho_g = lw[S_INV_RHO_G];
+    const float2 *Zs = Z + s * (int64_t)n * n;
+    float2 *Mg = Mbuf + s * ((int64_t)Dimg * Dimg + Dimg + 1);
+    const int ntri = n * (n + 1) / 2;
+    for (int t = tid; t < ntri; t += PR_THREADS) {
+        int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        if (i * (i + 1) / 2 > t) --i;
+        if ((i + 1) * (i + 2) / 2 <= t) ++i;
+        const int j = t - i * (i + 1) / 2;
+        const float2 zn = Zs[(int64_t)i * n + j];
+        half_image_store(Mg, D, Dimg, i, j, zn, corner_g, inv_rho_g, (i == D && j < D) ? phi[s * D + j] : make_float2(0.f, 0.f),
+                         i < D ? h[s * D + i] : 0.f);
+    }
+    if (Dimg > D) half_image_pad(Mg, D, Dimg, tid, PR_THREADS);
 }
 
 template <bool TRI>
@@ -225,30 +281,11 @@ __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
                     zn = make_float2(zv[q].x + al * (gv[q].x - c.x), zv[q].y + al * (gv[q].y - c.y));
                     Zs[idx] = zn;
                 }
-                if (i == D) {
-                    if (j == D) Mg[(int64_t)Dimg * Dimg + Dimg] = make_float2(corner_g - inv_rho_g * zn.x, -inv_rho_g * zn.y);
-                    else Mg[(int64_t)Dimg * Dimg + j] = make_float2(phis[j].x - inv_rho_g * zn.x, phis[j].y + inv_rho_g * zn.y);   // A[j][D] = conj(A[D][j])
-                } else {
-                    const float2 a = make_float2((i == j ? hs[i] : 0.f) - inv_rho_g * zn.x, -inv_rho_g * zn.y);
-                    Mg[(int64_t)i * Dimg + j] = a;
-                    if (i != j && (i >> 4) == (j >> 4)) Mg[(int64_t)j * Dimg + i] = make_float2(a.x, -a.y);
-                }
+                if (!(mode & PM_NOIMG))
+                    half_image_store(Mg, D, Dimg, i, j, zn, corner_g, inv_rho_g, (i == D && j < D) ? phis[j] : zero2, i < D ? hs[i] : 0.f);
             }
         }
-        if (Dimg > D) {   // (uniform) the padding: rows D .. Dimg - 1 of the lower 16-block triangle (whole diagonal blocks:
-                          // the block that holds row D also gets its columns >= D), the arrow entries behind D
-            const int pad = Dimg - D;
-            for (int t = tid; t < pad * Dimg; t += PR_THREADS) {
-                const int i = D + t / Dimg, j = t - (i - D) * Dimg;
-                if ((j >> 4) <= (i >> 4)) Mg[(int64_t)i * Dimg + j] = zero2;
-            }
-            const int i0 = D & ~15;                      // rows of the block that holds row D, above it
-            for (int t = tid; t < (D - i0) * 16; t += PR_THREADS) {
-                const int i = i0 + (t >> 4), j = i0 + (t & 15);
-                if (j >= D) Mg[(int64_t)i * Dimg + j] = zero2;
-            }
-            for (int j = D + tid; j < Dimg; j += PR_THREADS) Mg[(int64_t)Dimg * Dimg + j] = zero2;
-        }
+        if (Dimg > D && !(mode & PM_NOIMG)) half_image_pad(Mg, D, Dimg, tid, PR_THREADS);   // (uniform)
         return;
     }
     for (int idx = tid; idx < n * n; idx += PR_THREADS) {
@@ -336,7 +373,7 @@ int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const flo
 
 int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2 *y, const float2 *b,
                 const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st,
-                bool no_matrix, bool lean) {
+                bool no_matrix, bool lean, bool no_image) {
     ProfScope _prof(KC_PREP, st);
     if (nb <= 0) return ADMMNET_OK;
     const int D = cfg->M * cfg->N, n = D + 1;
@@ -349,6 +386,7 @@ int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2
     if (phi_only) mode |= PM_PHI_ONLY;
     if (no_matrix && k == 0) mode |= PM_NO_MATRIX;
     if (lean) mode |= (D > 128) ? PM_HALF : PM_LEAN;
+    if (no_image && (mode & PM_HALF)) mode |= PM_NOIMG;
     const int cur = k & 1, prv = cur ^ 1;
     const size_t lds = sizeof(float2) * 2 * D + sizeof(float) * (3 * D + kHid + 8);
     auto kern = (mode & PM_HALF) ? prep_kernel<true> : prep_kernel<false>;
@@ -356,6 +394,15 @@ int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2
                        y + b0 * D, b + b0 * D, sigma + b0, ws.G + b0 * (int64_t)n * n,
                        ws.Z + b0 * (int64_t)n * n, ws.phi[prv] + b0 * D, ws.h[prv] + b0 * D, ws.alpha + b0,
                        ws.phi[cur] + b0 * D, ws.h[cur] + b0 * D, ws.Mbuf, eig_dim(D));
+    ADMM_HIP(hipGetLastError());
+    return ADMMNET_OK;
+}
+
+int launch_half_image(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, const float2 *Z, const Ws &ws,
+                      hipStream_t st) {
+    ProfScope _prof(KC_PREP, st);
+    if (nb <= 0) return ADMMNET_OK;
+    hipLaunchKernelGGL(half_image_kernel, dim3((unsigned)nb), dim3(PR_THREADS), 0, st, D, eig_dim(D), lw, phi, h, Z, ws.Mbuf, ws.skip);
     ADMM_HIP(hipGetLastError());
     return ADMMNET_OK;
 }

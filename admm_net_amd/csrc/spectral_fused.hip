@@ -264,7 +264,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
                 dst[2 * i + ((lane >> 4) & 1)] = t;
             }
         };
-        // two rows per trip, the next two in flight behind them (the loads are the latency that bounds this phase)
+        // two rows per trip, the next two in flight behind them (the loads are what bounds this phase)
         load_row(wave, za);
         load_row(wave + SF_WAVES, zb);
         for (int i = wave; i < n; i += 2 * SF_WAVES) {
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             return a;
         };
         {   // L region: three row pairs per sweep, 256 columns each; the loads of three sweeps in flight together
-            constexpr int RP = SF_THREADS / 256, LQ = (16 + RP - 1) / RP, LB = 3;
+            constexpr int RP = SF_THREADS / 256, LQ = (16 + RP - 1) / RP, LB = LQ;   // (all sweeps' loads in one round)
 #pragma unroll
             for (int qb = 0; qb < LQ; qb += LB) {
                 float2 zl0[LB], zl1[LB];
@@ -460,20 +460,20 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
                 ETim32[j * P32 + kp] = sf_pack_bf16(e0.y, 0.f);
             }
         }
-        {   // U region: 48 rows of Z per sweep (16 lanes per row), two sweeps' loads in flight
-            constexpr int RPS = SF_THREADS / 16;
+        {   // U region: 48 rows of Z per sweep (16 lanes per row), the loads of three sweeps in flight
+            constexpr int RPS = SF_THREADS / 16, UB = 3;
             const int kp = tl & 15, k = k0 + 2 * kp;
-            for (int jb = k0 + 1; jb < n; jb += 2 * RPS) {
-                float2 zu0[2], zu1[2];
+            for (int jb = k0 + 1; jb < n; jb += UB * RPS) {
+                float2 zu0[UB], zu1[UB];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < UB; ++u) {
                     const int j = jb + RPS * u + (tl >> 4);
                     const bool v = j < n && j >= k + 1;
                     zu0[u] = v ? Z[(int64_t)j * n + k] : make_float2(0.f, 0.f);
                     zu1[u] = (v && k + 1 < n) ? Z[(int64_t)j * n + k + 1] : make_float2(0.f, 0.f);
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < UB; ++u) {
                     const int j = jb + RPS * u + (tl >> 4);
                     if (j < n && j >= k + 1) {
                         const float hj = cv.hh[j];
@@ -628,16 +628,17 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             if (wave * TPW + s < ntri) {
                 const int gj = 32 * tJ[s] + r32;
                 const float2 vj0 = cv.X0[gj < n ? gj : 0], vj1 = cv.X1[gj < n ? gj : 0];
+                constexpr int AB = 16;
 #pragma unroll
-                for (int qb = 0; qb < 16; qb += 8) {
-                    float2 zq[8];
+                for (int qb = 0; qb < 16; qb += AB) {
+                    float2 zq[AB];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {   // (the loads of half a tile first)
+                    for (int u = 0; u < AB; ++u) {   // (the loads of the tile first)
                         const int q = qb + u, gi = 32 * tI[s] + (q & 3) + 8 * (q >> 2) + 4 * kh;
                         zq[u] = (gi < D && gj <= gi) ? Z[(int64_t)gi * n + gj] : make_float2(0.f, 0.f);
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < AB; ++u) {
                         const int q = qb + u, gi = 32 * tI[s] + (q & 3) + 8 * (q >> 2) + 4 * kh;
                         if (gi < D && gj <= gi) {
                             const float hi = cv.hh[gi];

@@ -22,6 +22,7 @@ CLASSES = {   # kernel classes of bench.py -> kernel names (D = 256 route; D <= 
     "backtransform": ["wy_apply_kernel", "wy_lastcol_kernel"],
     "rebuild": ["rebuild_big_kernel", "back_rebuild_kernel"],
     "prep": ["prep_kernel"],
+    "gfunction": ["sp_fused_kernel"],   # the G-layer as a matrix function (default route): profile it with `only=gfunction,prep`
 }
 
 
@@ -33,8 +34,14 @@ def main():
     def val(r, k):
         return float(r[k]) if r.get(k) not in (None, "") else 0.0
 
+    only = None   # optional 4th argument "only=cls1,cls2": merge just these classes into the workload's existing entry
+    for a in sys.argv[4:]:
+        if a.startswith("only="):
+            only = a[5:].split(",")
     out = {}
     for cls, names in CLASSES.items():
+        if only and cls not in only:
+            continue
         rs = [r for r in rows if any(r["Kernel"].startswith(nm) for nm in names)]
         if not rs:
             continue
@@ -57,7 +64,12 @@ def main():
         out[cls] = e
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "traffic.json")
     t = json.load(open(path))
-    t["workloads"][wl] = {"batch_profiled": int(mats), "round": 3, "source": os.path.basename(src), "kernels": out}
+    if only and wl in t["workloads"]:
+        for cls, e in out.items():
+            e["source"] = os.path.basename(src)
+            t["workloads"][wl]["kernels"][cls + ("_matrix_function_route" if cls == "prep" else "")] = e
+    else:
+        t["workloads"][wl] = {"batch_profiled": int(mats), "round": 3, "source": os.path.basename(src), "kernels": out}
     json.dump(t, open(path, "w"), indent=1)
     tot = sum(e["traffic_bytes_per_matrix"] for e in out.values())
     print("total HBM bytes per matrix and layer: %.2f MB" % (tot / 1e6))
