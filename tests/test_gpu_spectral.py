@@ -32,7 +32,7 @@ def _oracle(Nb, Nd, K, B, perturb, seed=5):
 @pytest.mark.skipif(os.environ.get("ADMMNET_SPECTRAL") == "0", reason="the route is switched off")
 @pytest.mark.parametrize("Nb,Nd,K,B,perturb", [(10, 10, 10, 48, 0.0), (10, 10, 10, 48, 0.3), (8, 16, 8, 32, 0.3),
                                                 (16, 16, 8, 12, 0.0), (16, 16, 8, 12, 0.3), (12, 16, 6, 12, 0.3),
-                                                (4, 4, 6, 32, 0.3), (5, 7, 6, 16, 0.2)])
+                                                (4, 4, 6, 32, 0.3), (5, 7, 6, 16, 0.2), (10, 10, 8, 32, 1.0)])
 def test_matrix_function_route_matches_the_f64_oracle(Nb, Nd, K, B, perturb):
     import admm_net_amd as A
     dev = torch.device("cuda:0")
