@@ -434,7 +434,10 @@ int launch_spectral(int D, int64_t nb, const float *lw, const float2 *phi, const
     ProfScope _prof(KC_GFUNC, st);
     if (nb <= 0) return ADMMNET_OK;
     const int n = D + 1;
-    static const float tol = getenv("ADMMNET_SPECTRAL_TOL") ? (float)atof(getenv("ADMMNET_SPECTRAL_TOL")) : 3e-7f;
+    // model tolerance: the quadratic may miss f on the bulk by 1e-6 of the result's scale -- below the eigensolver route's own
+    // rounding per layer (~2e-6) and without effect on the distance to the float64 oracle (3e-7, 1e-6 and 3e-6 measured the same:
+    // tests/gpu_spectral_check.py); at K = 32 the tighter 3e-7 rejected 3.0 % of the matrix-layers, this one 0.4 %
+    static const float tol = getenv("ADMMNET_SPECTRAL_TOL") ? (float)atof(getenv("ADMMNET_SPECTRAL_TOL")) : 1e-6f;
     if (use_spectral_fused()) {
         if (!ws.spec_flag || !lower_only) {
             set_error("spectral: the fused kernel needs the flag buffer and the lower-triangle state");
