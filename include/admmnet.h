@@ -98,8 +98,12 @@ int64_t admmnet_workspace_bytes(const admmnet_cfg *cfg, int64_t B);
  *   sigma     device float32   [B]
  *   phi_out   device complex64 [B][D]
  *   head_out  device float32   [3][B][L] (tau, f, confidence) or NULL
- *   status    device int32     [4] or NULL: [0] = #matrices whose eigensolver
- *             failed (must be 0), others reserved.  Zeroed by the call.
+ *   status    device int32     [4] or NULL, zeroed by the call: [0] = #matrices whose eigensolver
+ *             failed (must be 0).  The G-layer (admm_net.py:237-354: eigh, eigenvalue map f, V f(L) V^H) is
+ *             evaluated as a matrix function wherever the per-matrix checks of csrc/spectral.hip allow it
+ *             (ADMMNET_SPECTRAL=0: never) and through the eigensolver otherwise; [1] = #matrix-layers that
+ *             went through the eigensolver after a rejection, [2] = #matrix-layers evaluated as a matrix
+ *             function, [3] = of [1], those rejected because f is not a quadratic on the bulk of the spectrum.
  */
 int admmnet_forward_f32(const admmnet_cfg *cfg, const float *weights_dev,
                         const void *y, const void *b, const float *sigma,
