@@ -413,56 +413,77 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         asm volatile("" : "+v"(tl));
         // element pair (j; k, k + 1) of E^T: e_q = E[k + q][j].  j <= k: from rows k, k + 1 of Z (lanes over j);
         // j >= k + 1: conj of E[j][k + q] from row j of Z (lanes over k)
-        auto deflate = [&](float2 a, int row, int col) {   // E[row][col] from A[row][col] (row >= col)
-            const float2 vr0 = cv.X0[row], vc0 = cv.X0[col], vr1 = cv.X1[row], vc1 = cv.X1[col];
+        // (the vector elements every element of a thread shares -- its column in the L region, its row pair in the U region -- are read
+        //  from LDS once per slab, the pair-wise ones as one 16-byte read: the staging was bound by the LDS pipe, 14 LDS
+        //  instructions per element pair; now 5)
+        auto deflate = [&](float2 a, float2 vr0, float2 vc0, float2 vr1, float2 vc1, bool diag) {   // E[row][col] from A[row][col]
             const float2 q0 = cmulc(vr0, vc0), q1 = cmulc(vr1, vc1);
             a.x -= mu0 * q0.x + mu1 * q1.x;
             a.y -= mu0 * q0.y + mu1 * q1.y;
-            if (row == col) {
+            if (diag) {
                 a.x -= cf;
                 a.y = 0.f;
             }
             return a;
         };
-        {   // L region: three row pairs per sweep, 256 columns each; the loads of three sweeps in flight together
-            constexpr int RP = SF_THREADS / 256, LQ = (16 + RP - 1) / RP, LB = LQ;   // (all sweeps' loads in one round)
+        auto pair_of = [&](const float2 *v, int k, float2 &lo, float2 &hi) {   // v[k], v[k + 1] (k even: one 16-byte read)
+            const float4 t = *reinterpret_cast<const float4 *>(v + k);
+            lo = make_float2(t.x, t.y);
+            hi = make_float2(t.z, t.w);
+        };
+        {   // L region: three row pairs per sweep, 256 columns each; the loads of all sweeps in flight together
+            constexpr int RP = SF_THREADS / 256, LQ = (16 + RP - 1) / RP;
+            const int j = tl & 255;
+            const float2 vj0 = cv.X0[j], vj1 = cv.X1[j], phj = cv.ph[j];   // (j <= 255 < NP)
+            constexpr int LB = 3;
 #pragma unroll
             for (int qb = 0; qb < LQ; qb += LB) {
-                float2 zl0[LB], zl1[LB];
+            float2 zl0[LB], zl1[LB];
 #pragma unroll
-                for (int u = 0; u < LB; ++u) {
-                    const int kp = RP * (qb + u) + (tl >> 8), j = tl & 255;
-                    const int k = k0 + 2 * kp;
-                    const bool v = kp < 16 && j <= k && j < n;
-                    zl0[u] = (v && k < n) ? Z[(int64_t)k * n + j] : make_float2(0.f, 0.f);
-                    zl1[u] = (v && k + 1 < n) ? Z[(int64_t)(k + 1) * n + j] : make_float2(0.f, 0.f);
-                }
+            for (int uu = 0; uu < LB; ++uu) {
+                const int kp = RP * (qb + uu) + (tl >> 8);
+                const int k = k0 + 2 * kp;
+                const bool v = kp < 16 && j <= k && j < n;
+                zl0[uu] = (v && k < n) ? Z[(int64_t)k * n + j] : make_float2(0.f, 0.f);
+                zl1[uu] = (v && k + 1 < n) ? Z[(int64_t)(k + 1) * n + j] : make_float2(0.f, 0.f);
+            }
 #pragma unroll
-                for (int u = 0; u < LB; ++u) {
-                    const int kp = RP * (qb + u) + (tl >> 8), j = tl & 255;
-                    const int k = k0 + 2 * kp;
-                    if (kp < 16 && j <= k && j < n) {
-                        float2 e0 = make_float2(0.f, 0.f), e1 = e0;
-                        if (k < n) e0 = deflate(sf_a_elem(k, j, D, zl0[u], ir, corner, cv.hh[k], cv.ph[j]), k, j);
-                        if (k + 1 < n) e1 = deflate(sf_a_elem(k + 1, j, D, zl1[u], ir, corner, cv.hh[k + 1], cv.ph[j]), k + 1, j);
-                        ETre32[j * P32 + kp] = sf_pack_bf16(e0.x, e1.x);
-                        ETim32[j * P32 + kp] = sf_pack_bf16(e0.y, e1.y);
-                    }
+            for (int u = 0; u < LB; ++u) {
+                const int kp = RP * (qb + u) + (tl >> 8);
+                const int k = k0 + 2 * kp;
+                if (kp < 16 && j <= k && j < n) {
+                    float2 vk0, vk0b, vk1, vk1b;
+                    pair_of(cv.X0, k, vk0, vk0b);     // (k + 1 <= 257 + 30 < the padded length only for k < NP - 1: see below)
+                    pair_of(cv.X1, k, vk1, vk1b);
+                    const float2 hk = *reinterpret_cast<const float2 *>(cv.hh + k);
+                    float2 e0 = make_float2(0.f, 0.f), e1 = e0;
+                    if (k < n) e0 = deflate(sf_a_elem(k, j, D, zl0[u], ir, corner, hk.x, phj), vk0, vj0, vk1, vj1, k == j);
+                    if (k + 1 < n) e1 = deflate(sf_a_elem(k + 1, j, D, zl1[u], ir, corner, hk.y, phj), vk0b, vj0, vk1b, vj1, k + 1 == j);
+                    ETre32[j * P32 + kp] = sf_pack_bf16(e0.x, e1.x);
+                    ETim32[j * P32 + kp] = sf_pack_bf16(e0.y, e1.y);
                 }
+            }
             }
         }
         if (tl < 16 && D >= 256) {   // (the L sweep covers j <= 255: the corner element j = k = D = 256 of the last slab)
             const int kp = tl, k = k0 + 2 * kp, j = 256;
             if (j <= k && j < n) {   // (k = 256: the corner; k > 256: padding of the k dimension)
                 float2 e0 = make_float2(0.f, 0.f);
-                if (k < n) e0 = deflate(sf_a_elem(k, j, D, Z[(int64_t)k * n + j], ir, corner, cv.hh[k], cv.ph[j]), k, j);
+                if (k < n)
+                    e0 = deflate(sf_a_elem(k, j, D, Z[(int64_t)k * n + j], ir, corner, cv.hh[k], cv.ph[j]), cv.X0[k], cv.X0[j], cv.X1[k],
+                                 cv.X1[j], k == j);
                 ETre32[j * P32 + kp] = sf_pack_bf16(e0.x, 0.f);
                 ETim32[j * P32 + kp] = sf_pack_bf16(e0.y, 0.f);
             }
         }
         {   // U region: 48 rows of Z per sweep (16 lanes per row), the loads of three sweeps in flight
-            constexpr int RPS = SF_THREADS / 16, UB = 3;
+            constexpr int RPS = SF_THREADS / 16, UB = 2;
             const int kp = tl & 15, k = k0 + 2 * kp;
+            const int kc = k < NP - 1 ? k : 0;   // (slab positions beyond the matrix: their pairs are never used)
+            float2 vk0, vk0b, vk1, vk1b, phk, phkb;
+            pair_of(cv.X0, kc, vk0, vk0b);
+            pair_of(cv.X1, kc, vk1, vk1b);
+            pair_of(cv.ph, kc, phk, phkb);
             for (int jb = k0 + 1; jb < n; jb += UB * RPS) {
                 float2 zu0[UB], zu1[UB];
 #pragma unroll
@@ -477,9 +498,11 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
                     const int j = jb + RPS * u + (tl >> 4);
                     if (j < n && j >= k + 1) {
                         const float hj = cv.hh[j];
-                        float2 e0 = deflate(sf_a_elem(j, k, D, zu0[u], ir, corner, hj, cv.ph[k]), j, k), e1 = make_float2(0.f, 0.f);
+                        const float2 vj0 = cv.X0[j], vj1 = cv.X1[j];
+                        float2 e0 = deflate(sf_a_elem(j, k, D, zu0[u], ir, corner, hj, phk), vj0, vk0, vj1, vk1, false);
+                        float2 e1 = make_float2(0.f, 0.f);
                         if (k + 1 < n)   // (k + 1 <= j; equal: the diagonal element)
-                            e1 = deflate(sf_a_elem(j, k + 1, D, zu1[u], ir, corner, hj, cv.ph[k + 1]), j, k + 1);
+                            e1 = deflate(sf_a_elem(j, k + 1, D, zu1[u], ir, corner, hj, phkb), vj0, vk0b, vj1, vk1b, j == k + 1);
                         ETre32[j * P32 + kp] = sf_pack_bf16(e0.x, e1.x);     // E[k][j] = conj(E[j][k])
                         ETim32[j * P32 + kp] = sf_pack_bf16(-e0.y, -e1.y);
                     }
