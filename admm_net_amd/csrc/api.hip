@@ -517,10 +517,18 @@ int admmnet_layer_front(const admmnet_cfg *cfg, const float *W, int32_t k, const
         // only runs the matrices it flagged
         const bool spec = use_spectral() && wc.spec_flag && lean && D >= 8 && (D > 128 || fused);
         const bool late_image = spec && D > 128 && use_spectral_fused();   // (the image only for the flagged matrices, afterwards)
-        if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, wc, false, sc, false, lean, late_image))) return rc;
+        // the lazy Z update of the previous layer rides the first sweep of the fused kernel: prep then only computes phi and h
+        static const bool fold_env = !(getenv("ADMMNET_SF_FOLD") && atoi(getenv("ADMMNET_SF_FOLD")) == 0);
+        const bool fold = spec && use_spectral_fused() && fold_env && k >= 1;
+        if ((rc = launch_prep(cfg, W, k, yy, bb, sigma, b0, nb, wc, false, sc, false, lean, late_image, fold))) return rc;
         Ws wf = wc;
         if (spec) {
-            if ((rc = launch_spectral(D, nb, lw, phk, hk, ws.Z + b0 * n * n, Gk, ws.rn + b0, wc, status, sc, true))) return rc;
+            const int prv = cur ^ 1;
+            const float *lwp = k >= 1 ? W + (int64_t)(k - 1) * L.size() : lw;
+            if ((rc = launch_spectral(D, nb, lw, phk, hk, ws.Z + b0 * n * n, Gk, ws.rn + b0, wc, status, sc, true,
+                                      fold ? ws.alpha + b0 : nullptr, fold ? ws.phi[prv] + b0 * D : nullptr,
+                                      fold ? ws.h[prv] + b0 * D : nullptr, fold ? lwp : nullptr, fold ? (k == 1 ? 2 : 1) : 0)))
+                return rc;
             wf.skip = wc.spec_flag;
             if (late_image && (rc = launch_half_image(D, nb, lw, phk, hk, ws.Z + b0 * n * n, wf, sc))) return rc;
         }

@@ -123,7 +123,8 @@ int64_t pick_chunk(const admmnet_cfg *cfg, int64_t B);
 // prep.hip
 int launch_prep(const admmnet_cfg *cfg, const float *lw, int k, const float2 *y, const float2 *b,
                 const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st,
-                bool no_matrix = false, bool lean = false, bool no_image = false);
+                bool no_matrix = false, bool lean = false, bool no_image = false, bool small = false);
+// (small: phi and h only -- the Z update of the previous layer is then the matrix-function kernel's, launch_spectral's `update`)
 // (no_image, D > 128 lean route: only the Z update streams; launch_half_image then builds the image of the matrices with
 //  ws.skip[s] != 0 from the updated Z)
 int launch_half_image(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, const float2 *Z, const Ws &ws,
@@ -194,10 +195,14 @@ int launch_spectrum_main(const float2 *phi, int64_t B, int xbase, int ybase, con
 // spectral.hip
 bool use_spectral();
 bool use_spectral_fused();   // spectral_fused.hip: the whole evaluation in one kernel (default when the path is on)
-int launch_spectral_fused(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, const float2 *Z, float2 *G,
-                          float *rn, int *flag, int32_t *status, float tol, hipStream_t st);
-int launch_spectral(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, const float2 *Z, float2 *G,
-                    float *rn, const Ws &ws, int32_t *status, hipStream_t st, bool lower_only);
+int launch_spectral_fused(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *Z, float2 *G,
+                          float *rn, int *flag, int32_t *status, float tol, const float *alpha, const float2 *phi_prev,
+                          const float *h_prev, const float *lw_prev, int update_mode, hipStream_t st);
+// update_mode 0: Z is current; 1 / 2: the fused kernel applies Z <- Z + alpha (G - C_prev) in its first sweep (2: stored Z still zero)
+int launch_spectral(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *Z, float2 *G,
+                    float *rn, const Ws &ws, int32_t *status, hipStream_t st, bool lower_only, const float *alpha = nullptr,
+                    const float2 *phi_prev = nullptr, const float *h_prev = nullptr, const float *lw_prev = nullptr,
+                    int update_mode = 0);
 // vdvh.hip (training route)
 int launch_vdvh(int n, int64_t nb, const float2 *V, const float *d, float2 *out, hipStream_t st);
 int launch_vhsv(int n, int64_t nb, const float2 *V, const float2 *S, float *q, hipStream_t st);

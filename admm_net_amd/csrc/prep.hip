@@ -50,6 +50,7 @@ constexpr int PM_HALF = 32;      // D = 256 (tridiag_panel.hip): G / Z streamed 
                                  // 16-block triangle only (diagonal blocks in full) -- the tiles that kernel loads
 constexpr int PM_NOIMG = 64;     // with PM_HALF: only the lazy Z update streams, no image -- the G-layer is evaluated as a matrix function
                                  // straight from Z (spectral_fused.hip); the matrices it rejects get their image from half_image_kernel
+constexpr int PM_SMALL = 128;    // phi and h only: the lazy Z update is folded into the first sweep of the matrix-function kernel
 constexpr int PM_LEAN = 16;      // G / Z kept as lower triangles, A built by the tridiagonalisation's own loader
                                  // (tridiag_reg.hip): only the lazy Z update streams here, 24 n^2 / 2 bytes per signal
 
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(PR_THREADS) void prep_kernel(
     }
     __syncthreads();
 
-    if (mode & PM_NO_MATRIX) return;
+    if (mode & (PM_NO_MATRIX | PM_SMALL)) return;
     if (mode & PM_LEAN) {
         // Z <- Z + alpha (G - C_prev) on the lower triangle (row D = arrow row).  Two rows per trip, one per
         // half of the workgroup: row r (r + 1 entries) and row n - 1 - r, so both halves stay busy.
@@ -373,7 +374,7 @@ int launch_build_block(int D, int64_t nb, float corner, float inv_rho, const flo
 
 int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2 *y, const float2 *b,
                 const float *sigma, int64_t b0, int64_t nb, const Ws &ws, bool phi_only, hipStream_t st,
-                bool no_matrix, bool lean, bool no_image) {
+                bool no_matrix, bool lean, bool no_image, bool small) {
     ProfScope _prof(KC_PREP, st);
     if (nb <= 0) return ADMMNET_OK;
     const int D = cfg->M * cfg->N, n = D + 1;
@@ -387,6 +388,7 @@ int launch_prep(const admmnet_cfg *cfg, const float *lw_all, int k, const float2
     if (no_matrix && k == 0) mode |= PM_NO_MATRIX;
     if (lean) mode |= (D > 128) ? PM_HALF : PM_LEAN;
     if (no_image && (mode & PM_HALF)) mode |= PM_NOIMG;
+    if (small) mode |= PM_SMALL;
     const int cur = k & 1, prv = cur ^ 1;
     const size_t lds = sizeof(float2) * 2 * D + sizeof(float) * (3 * D + kHid + 8);
     auto kern = (mode & PM_HALF) ? prep_kernel<true> : prep_kernel<false>;

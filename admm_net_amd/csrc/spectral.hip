@@ -429,8 +429,9 @@ __global__ __launch_bounds__(SP_THREADS) void sp_assemble_kernel(int D, const fl
 
 // Scratch of its own (Ws::spec_*, carved only when the path is on).  Returns with flag[] filled; the caller runs the
 // eigen-pipeline with Ws::skip = flag.
-int launch_spectral(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, const float2 *Z, float2 *G,
-                    float *rn, const Ws &ws, int32_t *status, hipStream_t st, bool lower_only) {
+int launch_spectral(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *Z, float2 *G,
+                    float *rn, const Ws &ws, int32_t *status, hipStream_t st, bool lower_only, const float *alpha,
+                    const float2 *phi_prev, const float *h_prev, const float *lw_prev, int update_mode) {
     ProfScope _prof(KC_GFUNC, st);
     if (nb <= 0) return ADMMNET_OK;
     const int n = D + 1;
@@ -443,7 +444,12 @@ int launch_spectral(int D, int64_t nb, const float *lw, const float2 *phi, const
             set_error("spectral: the fused kernel needs the flag buffer and the lower-triangle state");
             return ADMMNET_E_WORKSPACE;
         }
-        return launch_spectral_fused(D, nb, lw, phi, h, Z, G, rn, ws.spec_flag, status, tol, st);
+        return launch_spectral_fused(D, nb, lw, phi, h, Z, G, rn, ws.spec_flag, status, tol, alpha, phi_prev, h_prev, lw_prev,
+                                     update_mode, st);
+    }
+    if (update_mode) {
+        set_error("spectral: the multi-kernel form does not apply the Z update");
+        return ADMMNET_E_ARG;
     }
     if (!ws.spec_flag || !ws.spec_vec || !ws.spec_val || !ws.spec_mat) {
         set_error("spectral: workspace without the fast-path buffers");

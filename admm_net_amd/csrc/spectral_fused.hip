@@ -20,6 +20,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "lane_reduce.h"
 
@@ -27,7 +29,8 @@ namespace admmnet {
 
 constexpr int SF_THREADS = 768, SF_WAVES = 12;   // three waves per SIMD, 168 registers each: every phase is latency-bound
 constexpr int SF_PITCH = 40;   // bf16 per slab row: 32 k-values + 8 of padding (80 bytes: 16-byte aligned, spreads the banks)
-constexpr int SF_MAXM = 5;     // column chunks of 64 per row (n <= 257 + ...: ceil(257 / 64))
+constexpr int SF_MAXM = 4;     // column chunks of 64 per row: columns 0 .. 255; the one column beyond them -- the corner element of
+                               // row 256 at n = 257 -- is handled by a single lane (a fifth chunk would cost 2 registers in every row buffer)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -107,7 +110,7 @@ __device__ inline double sf_eig_map(double w, double thr, const float *vn) {   /
 struct SfCarve {
     int NP, NJ;
     float2 *X0, *X1, *Y0, *Y1, *ph, *Ob;
-    float *hh, *red, *coef;
+    float *hh, *hp, *red, *coef;
     double *sc;
     int *flags;
     float2 *part;          // [SF_WAVES][2][NP]   (P1)
@@ -121,7 +124,7 @@ struct SfCarve {
     }
     __host__ __device__ static size_t bytes(int n) {
         const size_t NP = np_of(n), NJ = nj_of(n);
-        const size_t fixed = sizeof(float2) * 6 * NP + sizeof(float) * NP + sizeof(float) * 96 + sizeof(float) * 16 +
+        const size_t fixed = sizeof(float2) * 6 * NP + sizeof(float) * 2 * NP + sizeof(float) * 96 + sizeof(float) * 16 +
                              sizeof(double) * 16 + sizeof(int) * 4;
         const size_t part = sizeof(float2) * SF_WAVES * 2 * NP;
         const size_t slab = sizeof(unsigned short) * 2 * NJ * SF_PITCH;
@@ -134,18 +137,30 @@ struct SfCarve {
         X0 = reinterpret_cast<float2 *>(sc + 16);
         X1 = X0 + NP; Y0 = X1 + NP; Y1 = Y0 + NP; ph = Y1 + NP; Ob = ph + NP;
         hh = reinterpret_cast<float *>(Ob + NP);
-        red = hh + NP;                                              // 96 floats
+        hp = hh + NP;                                               // previous layer's h (lazy Z update)
+        red = hp + NP;                                              // 96 floats
         coef = red + 96;                                            // 16 floats
         flags = reinterpret_cast<int *>(coef + 16);                 // 4 ints
         // (offsets, not pointer arithmetic through integers: the compiler must keep seeing LDS addresses -- a round trip through
         //  uintptr_t turned every slab access into a flat_load with a 64-bit address that it then spilled around the MFMAs)
-        const int fixed = (int)(sizeof(double) * 16 + sizeof(float2) * 6 * NP + sizeof(float) * NP + sizeof(float) * 112 +
+        const int fixed = (int)(sizeof(double) * 16 + sizeof(float2) * 6 * NP + sizeof(float) * 2 * NP + sizeof(float) * 112 +
                                 sizeof(int) * 4);
         char *u = smem + ((fixed + 15) & ~15);
         part = reinterpret_cast<float2 *>(u);
         ETre = reinterpret_cast<unsigned short *>(u);
         ETim = ETre + NJ * SF_PITCH;
     }
+};
+
+// The lazy Z update of the previous layer, folded into the first sweep (prep_kernel then only computes phi and h):
+//   Z <- Z + alpha_b (G - C_prev),  C_prev = [[diag h_prev, phi_prev], [phi_prev^H, corner_z of the previous layer]]   (admm_net.py:400-412)
+// mode 0: Z is current (prep streamed it); 1: update; 2: update with the stored Z still zero (layer 1: never written).
+struct SfUpdate {
+    const float *alpha;        // [B] step of the previous layer
+    const float2 *phi_prev;    // [B][D]
+    const float *h_prev;       // [B][D]
+    const float *lw_prev;      // packed weights of the previous layer (S_CORNER_Z)
+    int mode;
 };
 
 // A_ij (i >= j) of the layer matrix from the state element z = Z_ij
@@ -161,10 +176,10 @@ __device__ __forceinline__ float2 sf_a_elem(int i, int j, int D, float2 z, float
 
 template <int TPW>
 __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const float *__restrict__ lw, const float2 *__restrict__ phi,
-                                                                 const float *__restrict__ h, const float2 *__restrict__ Zg,
-                                                                 float2 *__restrict__ G, float *__restrict__ rn,
+                                                                 const float *__restrict__ h, float2 *Zg,
+                                                                 float2 *G, float *__restrict__ rn,
                                                                  int *__restrict__ flag, int32_t *__restrict__ status, float tol,
-                                                                 int iters, unsigned long long *__restrict__ ptime) {
+                                                                 int iters, unsigned long long *__restrict__ ptime, SfUpdate up) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // developer phase timer (ADMMNET_SF_TIMING=1): cycles of thread 0 between marks
     long long t_prev = ptime ? clock64() : 0;
@@ -179,7 +194,8 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
     const SfCarve cv(smem, n);
     const int NP = cv.NP;
     const int64_t b = blockIdx.x;
-    const float2 *Z = Zg + b * (int64_t)n * n;
+    float2 *Z = Zg + b * (int64_t)n * n;
+    const float2 *Gold = G + b * (int64_t)n * n;   // (read only in the first pass, with up.mode: G of the previous layer)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float ir = lw[S_INV_RHO_G], corner = lw[S_CORNER_G];
@@ -193,7 +209,13 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         cv.ph[tid] = p;
         cv.hh[tid] = tid < D ? h[b * D + tid] : 0.f;
         pn = p.x * p.x + p.y * p.y;
+        if (up.mode) {   // C of the previous layer for the lazy Z update (Ob is free until the border rows are written)
+            cv.Ob[tid] = tid < D ? up.phi_prev[b * D + tid] : make_float2(0.f, 0.f);
+            cv.hp[tid] = tid < D ? up.h_prev[b * D + tid] : 0.f;
+        }
     }
+    const float al = up.mode ? up.alpha[b] : 0.f;
+    const float corner_zp = up.mode ? up.lw_prev[S_CORNER_Z] : 0.f;
     {
         float z1 = 0.f, z2 = 0.f, z3 = 0.f;
         sf_block_sum4(pn, z1, z2, z3, cv.red);
@@ -208,12 +230,6 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
 
     mark(0);
     // ---- P1: subspace iteration ---------------------------------------------------------------------------------------------
-    float2 phr[SF_MAXM];
-#pragma unroll
-    for (int m = 0; m < SF_MAXM; ++m) {
-        const int j = lane + 64 * m;
-        phr[m] = (m < MM && j < D) ? cv.ph[j] : make_float2(0.f, 0.f);
-    }
     double trace = 0.0;
     float l0 = 0.f, l1 = 0.f, cf = 0.f, res0 = 0.f, res1 = 0.f;
     // at least two passes, then until both Ritz pairs have residuals below 2e-6 of their gap to the bulk (the acceptance test of
@@ -231,15 +247,43 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             c1[m] = v2f{0.f, 0.f};
         }
         float trl = 0.f;
+        // (the sweep in two instances: the first pass with the folded Z update carries the rows of the old G as well; the others
+        //  must not pay for its registers)
+        auto run_pass = [&](auto updc) {
+        constexpr bool UPD = decltype(updc)::value;
         float2 za[SF_MAXM], zb[SF_MAXM], zc[SF_MAXM], zd[SF_MAXM];
-        auto load_row = [&](int i, float2(&z)[SF_MAXM]) {
+        float2 ga[SF_MAXM], gb[SF_MAXM], gc[SF_MAXM], gd[SF_MAXM];   // (first pass with the Z update: the rows of the old G)
+        auto load_row = [&](int i, float2(&z)[SF_MAXM], float2(&g)[SF_MAXM]) {
 #pragma unroll
             for (int m = 0; m < SF_MAXM; ++m) {
                 const int j = lane + 64 * m;
-                z[m] = (i < n && j <= i) ? Z[(int64_t)i * n + j] : make_float2(0.f, 0.f);
+                const bool v = i < n && j <= i;
+                z[m] = (v && !(UPD && up.mode == 2)) ? Z[(int64_t)i * n + j] : make_float2(0.f, 0.f);
+                if (UPD) g[m] = v ? Gold[(int64_t)i * n + j] : make_float2(0.f, 0.f);
             }
         };
-        auto proc_row = [&](int i, const float2(&zc)[SF_MAXM]) {
+        auto proc_row = [&](int i, float2(&zc)[SF_MAXM], const float2(&gq)[SF_MAXM]) {
+            if (UPD) {   // Z <- Z + alpha (G - C_prev) for this row, written back; the rest of the kernel reads the new Z
+                const float hpi = cv.hp[i];
+#pragma unroll
+                for (int m = 0; m < SF_MAXM; ++m) {
+                    if (64 * m <= i) {
+                        const int j = lane + 64 * m;
+                        if (j <= i) {
+                            float2 c;
+                            if (i < D) c = make_float2(i == j ? hpi : 0.f, 0.f);
+                            else if (j == D) c = make_float2(corner_zp, 0.f);
+                            else {
+                                const float2 pp = cv.Ob[j];
+                                c = make_float2(pp.x, -pp.y);   // C[D][j] = conj(phi_prev_j)
+                            }
+                            const float2 zn = make_float2(zc[m].x + al * (gq[m].x - c.x), zc[m].y + al * (gq[m].y - c.y));
+                            zc[m] = zn;
+                            Z[(int64_t)i * n + j] = zn;
+                        }
+                    }
+                }
+            }
             const v2f xi0 = pk2(cv.X0[i]), xi1 = pk2(cv.X1[i]);
             const float hi = cv.hh[i];
             v2f r0 = {0.f, 0.f}, r1 = {0.f, 0.f};
@@ -247,7 +291,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             for (int m = 0; m < SF_MAXM; ++m) {
                 if (64 * m <= i) {   // (wave-uniform)
                     const int j = lane + 64 * m;
-                    float2 a = sf_a_elem(i, j, D, zc[m], ir, corner, hi, phr[m]);
+                    float2 a = sf_a_elem(i, j, D, zc[m], ir, corner, hi, (i == D && j < D) ? cv.ph[j] : make_float2(0.f, 0.f));
                     if (j > i) a = make_float2(0.f, 0.f);
                     if (j == i) trl += a.x;
                     const v2f av = pk2(a);
@@ -258,6 +302,20 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
                     c1[m] = pk_cfma_conj(c1[m], ac, xi1);
                 }
             }
+            if (i == 64 * SF_MAXM && lane == 0) {   // (n = 257, row 256) the corner element Z[256][256]: no chunk holds it
+                const int64_t idx = (int64_t)i * n + i;
+                float2 z = (UPD && up.mode == 2) ? make_float2(0.f, 0.f) : Z[idx];
+                if (UPD) {
+                    const float2 g = Gold[idx];
+                    z = make_float2(z.x + al * (g.x - corner_zp), z.y + al * g.y);
+                    Z[idx] = z;
+                }
+                const float a = corner - ir * z.x;          // (i = D here: D = 256 is the only geometry with a column 256)
+                trl += a;
+                const float2 xa = cv.X0[i], xb = cv.X1[i];
+                r0.x += a * xa.x; r0.y += a * xa.y;
+                r1.x += a * xb.x; r1.y += a * xb.y;
+            }
             const float t = sf_reduce4(r0.x, r0.y, r1.x, r1.y);
             if ((lane & 15) == 0) {   // rows of the wave: Y0.re, Y0.im, Y1.re, Y1.im of row i (this wave owns row i)
                 float *dst = reinterpret_cast<float *>((lane & 32) ? cv.Y1 : cv.Y0);
@@ -265,19 +323,24 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             }
         };
         // two rows per trip, the next two in flight behind them (the loads are what bounds this phase)
-        load_row(wave, za);
-        load_row(wave + SF_WAVES, zb);
+        load_row(wave, za, ga);
+        load_row(wave + SF_WAVES, zb, gb);
         for (int i = wave; i < n; i += 2 * SF_WAVES) {
-            load_row(i + 2 * SF_WAVES, zc);
-            load_row(i + 3 * SF_WAVES, zd);
-            proc_row(i, za);
-            if (i + SF_WAVES < n) proc_row(i + SF_WAVES, zb);
+            load_row(i + 2 * SF_WAVES, zc, gc);
+            load_row(i + 3 * SF_WAVES, zd, gd);
+            proc_row(i, za, ga);
+            if (i + SF_WAVES < n) proc_row(i + SF_WAVES, zb, gb);
 #pragma unroll
             for (int m = 0; m < SF_MAXM; ++m) {
                 za[m] = zc[m];
                 zb[m] = zd[m];
+                ga[m] = gc[m];
+                gb[m] = gd[m];
             }
         }
+        };
+        if (up.mode != 0 && it == 0) run_pass(std::true_type{});   // (uniform)
+        else run_pass(std::false_type{});
         // the mirrored part: per-wave partial sums, then one add per column
 #pragma unroll
         for (int m = 0; m < SF_MAXM; ++m) {
@@ -300,6 +363,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             y1e = cv.Y1[tid];
 #pragma unroll
             for (int w = 0; w < SF_WAVES; ++w) {
+                if (tid >= 64 * SF_MAXM) break;   // (column 256 has no mirrored part: nothing lies below the corner)
                 const float2 p0 = cv.part[(w * 2 + 0) * NP + tid], p1 = cv.part[(w * 2 + 1) * NP + tid];
                 y0e.x += p0.x; y0e.y += p0.y;
                 y1e.x += p1.x; y1e.y += p1.y;
@@ -714,8 +778,8 @@ bool use_spectral_fused() {
 }
 
 template <int TPW>
-static int sf_launch(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, const float2 *Z, float2 *G, float *rn,
-                     int *flag, int32_t *status, float tol, int iters, hipStream_t st) {
+static int sf_launch(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *Z, float2 *G, float *rn,
+                     int *flag, int32_t *status, float tol, int iters, const SfUpdate &up, hipStream_t st) {
     const size_t lds = SfCarve::bytes(D + 1);
     ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_fused_kernel<TPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
@@ -726,7 +790,7 @@ static int sf_launch(int D, int64_t nb, const float *lw, const float2 *phi, cons
         ADMM_HIP(hipMemsetAsync(ptime, 0, 16 * sizeof(unsigned long long), st));
     }
     hipLaunchKernelGGL((sp_fused_kernel<TPW>), dim3((unsigned)nb), dim3(SF_THREADS), lds, st, D, lw, phi, h, Z, G, rn, flag, status,
-                       tol, iters, ptime);
+                       tol, iters, ptime, up);
     ADMM_HIP(hipGetLastError());
     if (timing) {
         unsigned long long hb[16];
@@ -741,8 +805,10 @@ static int sf_launch(int D, int64_t nb, const float *lw, const float2 *phi, cons
     return ADMMNET_OK;
 }
 
-int launch_spectral_fused(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, const float2 *Z, float2 *G,
-                          float *rn, int *flag, int32_t *status, float tol, hipStream_t st) {
+int launch_spectral_fused(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *Z, float2 *G,
+                          float *rn, int *flag, int32_t *status, float tol, const float *alpha, const float2 *phi_prev,
+                          const float *h_prev, const float *lw_prev, int update_mode, hipStream_t st) {
+    const SfUpdate up{alpha, phi_prev, h_prev, lw_prev, update_mode};
     if (D < 2 || D > 256) {
         set_error("spectral: D=%d outside 2..256", D);
         return ADMMNET_E_ARG;
@@ -750,9 +816,9 @@ int launch_spectral_fused(int D, int64_t nb, const float *lw, const float2 *phi,
     static const int iters = getenv("ADMMNET_SPECTRAL_ITERS") ? atoi(getenv("ADMMNET_SPECTRAL_ITERS")) : 5;   // (upper bound)
     const int NT = (D + 31) >> 5, ntri = NT * (NT + 1) / 2, tpw = (ntri + SF_WAVES - 1) / SF_WAVES;
     switch (tpw) {
-        case 1: return sf_launch<1>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, st);
-        case 2: return sf_launch<2>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, st);
-        default: return sf_launch<3>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, st);
+        case 1: return sf_launch<1>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, up, st);
+        case 2: return sf_launch<2>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, up, st);
+        default: return sf_launch<3>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, up, st);
     }
 }
 

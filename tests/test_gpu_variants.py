@@ -58,6 +58,7 @@ VARIANTS = {
     "spectral_two_streams": {"ADMMNET_STREAMS": "2", "ADMMNET_TEST_CHUNK": "1"},
     "spectral_chunks": {"ADMMNET_TEST_CHUNK": "1"},
     "spectral_unfused": {"ADMMNET_SPECTRAL_FUSED": "0"},
+    "spectral_no_fold": {"ADMMNET_SF_FOLD": "0"},          # the lazy Z update streamed by prep_kernel instead of the kernel's first sweep
     "spectral_all_rejected": {"ADMMNET_SPECTRAL_TOL": "0"},
     "spectral_one_pass_cap": {"ADMMNET_SPECTRAL_ITERS": "1"},   # (one subspace pass cannot pass the residual check either)
 }
