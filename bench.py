@@ -253,12 +253,16 @@ def main():
         if fast:
             # the dominant kernel streams the lower triangles: ALGORITHMIC bytes per matrix-layer = Z in + G out, 8 n (n + 1) B
             # (DESIGN.md section 4); what it really moves is `traffic` (PMC), several sweeps of Z through the L2 / MALL
-            gbytes = 8.0 * n * (n + 1)
+            # (with the lazy Z update of the previous layer folded into its first sweep -- the default -- also G in + Z out: 16 n (n + 1) B)
+            folded = os.environ.get("ADMMNET_SF_FOLD") != "0" and os.environ.get("ADMMNET_SPECTRAL_FUSED") != "0"
+            gbytes = (16.0 if folded else 8.0) * n * (n + 1)
             ach_gbs = gbytes * mats_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roof = {"bound": "hbm", "kernel": "gfunction (sp_fused_kernel)", "achieved": round(ach_gbs, 2), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(ach_gbs / PEAK_HBM_GBS, 5), "traffic": traffic, "mfma_busy": mfma_busy,
                     "avg_launch_ms": round(avg_ms, 4), "matrices_per_launch": mats_per_launch,
                     "algorithmic_bytes_per_matrix": gbytes,
+                    "algorithmic_bytes_note": ("Z, G of the previous layer in; new Z, new G out (lower triangles, complex64)" if folded
+                                               else "Z in, G out (lower triangles, complex64)"),
                     "eigensolver_equivalent_tflops": round(F * value / world / 1e12, 3),
                     "eigensolver_equivalent_note": (
                         "value x the CANONICAL flop count of SURVEY 8(d) (24 n^3 per matrix-layer through an eigensolver): what an "
