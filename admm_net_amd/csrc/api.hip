@@ -131,7 +131,9 @@ struct Carver {
 // signals, padded vs sweep per forward: D = 160 306 vs 280 ms, D = 176 312 vs 368 ms, D = 192 319 vs 396 ms) -- ADMMNET_PAD_MIN
 // moves the switch.
 static int pad_min() {
-    static const int v = getenv("ADMMNET_PAD_MIN") ? atoi(getenv("ADMMNET_PAD_MIN")) : 176;
+    // (with the matrix-function route on -- the default -- the eigen-pipeline only sees the matrices it rejects, and the route needs
+    //  the lower-triangle state of the padded pipeline: every 128 < D < 256 is then padded, the crossover no longer matters)
+    static const int v = getenv("ADMMNET_PAD_MIN") ? atoi(getenv("ADMMNET_PAD_MIN")) : (use_spectral() ? 129 : 176);
     return v;
 }
 int eig_dim(int D) { return (D > 128 && D >= pad_min() && D < 256 && use_wy_back(256)) ? 256 : D; }
