@@ -57,31 +57,33 @@ __device__ __forceinline__ float sf_reduce4(float a, float b, float c, float d) 
 }
 
 // block-wide sums of four values: every thread gets all four (through LDS; two barriers)
-__device__ __forceinline__ void sf_block_sum4(float &a, float &b, float &c, float &d, float *red /* [4][SF_WAVES] */) {
+template <int W>
+__device__ __forceinline__ void sf_block_sum4(float &a, float &b, float &c, float &d, float *red /* [4][W] */) {
     const float t = sf_reduce4(a, b, c, d);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
-    if ((lane & 15) == 0) red[(lane >> 4) * SF_WAVES + wave] = t;
+    if ((lane & 15) == 0) red[(lane >> 4) * W + wave] = t;
     __syncthreads();
     float s[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < SF_WAVES; ++w) v += red[q * SF_WAVES + w];
+        for (int w = 0; w < W; ++w) v += red[q * W + w];
         s[q] = v;
     }
     a = s[0]; b = s[1]; c = s[2]; d = s[3];
 }
 
 // six values in one round (two barriers)
-__device__ __forceinline__ void sf_block_sum8(float &a, float &b, float &c, float &d, float &e, float &f, float *red /* [8][SF_WAVES] */) {
+template <int W>
+__device__ __forceinline__ void sf_block_sum8(float &a, float &b, float &c, float &d, float &e, float &f, float *red /* [8][W] */) {
     const float t = sf_reduce4(a, b, c, d), u = sf_reduce4(e, f, 0.f, 0.f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if ((lane & 15) == 0) {
-        red[(lane >> 4) * SF_WAVES + wave] = t;
-        red[(4 + (lane >> 4)) * SF_WAVES + wave] = u;
+        red[(lane >> 4) * W + wave] = t;
+        red[(4 + (lane >> 4)) * W + wave] = u;
     }
     __syncthreads();
     float s[6];
@@ -89,7 +91,7 @@ __device__ __forceinline__ void sf_block_sum8(float &a, float &b, float &c, floa
     for (int q = 0; q < 6; ++q) {
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < SF_WAVES; ++w) v += red[q * SF_WAVES + w];
+        for (int w = 0; w < W; ++w) v += red[q * W + w];
         s[q] = v;
     }
     a = s[0]; b = s[1]; c = s[2]; d = s[3]; e = s[4]; f = s[5];
@@ -113,7 +115,7 @@ struct SfCarve {
     float *hh, *hp, *red, *coef;
     double *sc;
     int *flags;
-    float2 *part;          // [SF_WAVES][2][NP]   (P1)
+    float2 *part;          // [waves][2][NP]      (P1)
     unsigned short *ETre;  // [NJ][SF_PITCH]      (P2 .. P3, aliases part)
     unsigned short *ETim;
     __host__ __device__ static int np_of(int n) { return (n + 7) & ~7; }
@@ -122,11 +124,11 @@ struct SfCarve {
         const int a = 32 * nt, b = (n + 7) & ~7;
         return a > b ? a : b;
     }
-    __host__ __device__ static size_t bytes(int n) {
+    __host__ __device__ static size_t bytes(int n, int W) {
         const size_t NP = np_of(n), NJ = nj_of(n);
         const size_t fixed = sizeof(float2) * 6 * NP + sizeof(float) * 2 * NP + sizeof(float) * 96 + sizeof(float) * 16 +
                              sizeof(double) * 16 + sizeof(int) * 4;
-        const size_t part = sizeof(float2) * SF_WAVES * 2 * NP;
+        const size_t part = sizeof(float2) * W * 2 * NP;
         const size_t slab = sizeof(unsigned short) * 2 * NJ * SF_PITCH;
         return fixed + (part > slab ? part : slab) + 64;
     }
@@ -174,8 +176,10 @@ __device__ __forceinline__ float2 sf_a_elem(int i, int j, int D, float2 z, float
     return a;
 }
 
-template <int TPW>
-__global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const float *__restrict__ lw, const float2 *__restrict__ phi,
+// W waves (64 W threads) per matrix: 12 for n > 129 (one workgroup per CU), 4 for n <= 129 -- three matrices per CU then overlap
+// each other's latencies (at those sizes the triangle stays in the L2 and the kernel is bound by its dependent phases)
+template <int TPW, int W>
+__global__ __launch_bounds__(64 * W, W == 12 ? 1 : 3) void sp_fused_kernel(int D, const float *__restrict__ lw, const float2 *__restrict__ phi,
                                                                  const float *__restrict__ h, float2 *Zg,
                                                                  float2 *G, float *__restrict__ rn,
                                                                  int *__restrict__ flag, int32_t *__restrict__ status, float tol,
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
     const float corner_zp = up.mode ? up.lw_prev[S_CORNER_Z] : 0.f;
     {
         float z1 = 0.f, z2 = 0.f, z3 = 0.f;
-        sf_block_sum4(pn, z1, z2, z3, cv.red);
+        sf_block_sum4<W>(pn, z1, z2, z3, cv.red);
     }
     const float ipn = pn > 0.f ? rsqrtf(pn) : 0.f;
     if (tid < NP) {
@@ -324,12 +328,12 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         };
         // two rows per trip, the next two in flight behind them (the loads are what bounds this phase)
         load_row(wave, za, ga);
-        load_row(wave + SF_WAVES, zb, gb);
-        for (int i = wave; i < n; i += 2 * SF_WAVES) {
-            load_row(i + 2 * SF_WAVES, zc, gc);
-            load_row(i + 3 * SF_WAVES, zd, gd);
+        load_row(wave + W, zb, gb);
+        for (int i = wave; i < n; i += 2 * W) {
+            load_row(i + 2 * W, zc, gc);
+            load_row(i + 3 * W, zd, gd);
             proc_row(i, za, ga);
-            if (i + SF_WAVES < n) proc_row(i + SF_WAVES, zb, gb);
+            if (i + W < n) proc_row(i + W, zb, gb);
 #pragma unroll
             for (int m = 0; m < SF_MAXM; ++m) {
                 za[m] = zc[m];
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         }
         if (it == 0) {
             float z1 = 0.f, z2 = 0.f, z3 = 0.f;
-            sf_block_sum4(trl, z1, z2, z3, cv.red);   // (barriers inside)
+            sf_block_sum4<W>(trl, z1, z2, z3, cv.red);   // (barriers inside)
             trace = (double)trl;
         }
         __syncthreads();
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             y0e = cv.Y0[tid];
             y1e = cv.Y1[tid];
 #pragma unroll
-            for (int w = 0; w < SF_WAVES; ++w) {
+            for (int w = 0; w < W; ++w) {
                 if (tid >= 64 * SF_MAXM) break;   // (column 256 has no mirrored part: nothing lies below the corner)
                 const float2 p0 = cv.part[(w * 2 + 0) * NP + tid], p1 = cv.part[(w * 2 + 1) * NP + tid];
                 y0e.x += p0.x; y0e.y += p0.y;
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         // H = X^H Y
         float h00 = x0e.x * y0e.x + x0e.y * y0e.y, h11 = x1e.x * y1e.x + x1e.y * y1e.y;
         float h01r = x0e.x * y1e.x + x0e.y * y1e.y, h01i = x0e.x * y1e.y - x0e.y * y1e.x;
-        sf_block_sum4(h00, h11, h01r, h01i, cv.red);
+        sf_block_sum4<W>(h00, h11, h01r, h01i, cv.red);
         // closed-form eigen-decomposition of [[h00, h01], [conj(h01), h11]] (every thread; fp32 like the sums it is made of)
         float ct = 1.f, st = 0.f, er = 1.f, ei = 0.f;
         {
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         const float2 p1 = make_float2(ny1.x - cf * nx1.x, ny1.y - cf * nx1.y);
         float n0 = p0.x * p0.x + p0.y * p0.y, n1 = p1.x * p1.x + p1.y * p1.y;
         float pr = p0.x * p1.x + p0.y * p1.y, pi = p0.x * p1.y - p0.y * p1.x;   // conj(p0) p1
-        sf_block_sum8(r0s, r1s, n0, n1, pr, pi, cv.red);
+        sf_block_sum8<W>(r0s, r1s, n0, n1, pr, pi, cv.red);
         res0 = sqrtf(r0s);
         res1 = sqrtf(r1s);
         last = it + 1 >= iters ||
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
     unsigned *ETre32 = reinterpret_cast<unsigned *>(cv.ETre), *ETim32 = reinterpret_cast<unsigned *>(cv.ETim);
     constexpr int P32 = SF_PITCH / 2;   // slab pitch in dwords
     // rows j >= n of the slab are operands of ignored outputs only: zero them once so that nothing non-finite is multiplied
-    for (int idx = tid; idx < (cv.NJ - n) * P32; idx += SF_THREADS) {
+    for (int idx = tid; idx < (cv.NJ - n) * P32; idx += (64 * W)) {
         ETre32[n * P32 + idx] = 0u;
         ETim32[n * P32 + idx] = 0u;
     }
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             hi = make_float2(t.z, t.w);
         };
         {   // L region: three row pairs per sweep, 256 columns each; the loads of all sweeps in flight together
-            constexpr int RP = SF_THREADS / 256, LQ = (16 + RP - 1) / RP;
+            constexpr int RP = (64 * W) / 256, LQ = (16 + RP - 1) / RP;
             const int j = tl & 255;
             const float2 vj0 = cv.X0[j], vj1 = cv.X1[j], phj = cv.ph[j];   // (j <= 255 < NP)
             constexpr int LB = 3;
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
             }
         }
         {   // U region: 48 rows of Z per sweep (16 lanes per row), the loads of three sweeps in flight
-            constexpr int RPS = SF_THREADS / 16, UB = 2;
+            constexpr int RPS = (64 * W) / 16, UB = 2;
             const int kp = tl & 15, k = k0 + 2 * kp;
             const int kc = k < NP - 1 ? k : 0;   // (slab positions beyond the matrix: their pairs are never used)
             float2 vk0, vk0b, vk1, vk1b, phk, phkb;
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
         }
         if (tid < n) fro += (tid < D ? 2.f : 1.f) * (ob.x * ob.x + ob.y * ob.y);
         float z1 = 0.f, z2 = 0.f, z3 = 0.f;
-        sf_block_sum4(fro, z1, z2, z3, cv.red);
+        sf_block_sum4<W>(fro, z1, z2, z3, cv.red);
     }
     const LayerLayout L{D};
     const float *vn = lw + L.off_vn();
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sp_fused_kernel(int D, const fl
     }
     {
         float z1 = 0.f, z2 = 0.f, z3 = 0.f;
-        sf_block_sum4(acc, z1, z2, z3, cv.red);
+        sf_block_sum4<W>(acc, z1, z2, z3, cv.red);
     }
     if (tid == 0) rn[b] = sqrtf(acc);
     mark(7);
@@ -777,11 +781,11 @@ bool use_spectral_fused() {
     return on;
 }
 
-template <int TPW>
+template <int TPW, int W>
 static int sf_launch(int D, int64_t nb, const float *lw, const float2 *phi, const float *h, float2 *Z, float2 *G, float *rn,
                      int *flag, int32_t *status, float tol, int iters, const SfUpdate &up, hipStream_t st) {
-    const size_t lds = SfCarve::bytes(D + 1);
-    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_fused_kernel<TPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const size_t lds = SfCarve::bytes(D + 1, W);
+    ADMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_fused_kernel<TPW, W>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
     static const bool timing = getenv("ADMMNET_SF_TIMING") != nullptr;   // developer aid, never on by default
     unsigned long long *ptime = nullptr;
@@ -789,7 +793,7 @@ static int sf_launch(int D, int64_t nb, const float *lw, const float2 *phi, cons
         ADMM_HIP(hipMalloc(&ptime, 16 * sizeof(unsigned long long)));
         ADMM_HIP(hipMemsetAsync(ptime, 0, 16 * sizeof(unsigned long long), st));
     }
-    hipLaunchKernelGGL((sp_fused_kernel<TPW>), dim3((unsigned)nb), dim3(SF_THREADS), lds, st, D, lw, phi, h, Z, G, rn, flag, status,
+    hipLaunchKernelGGL((sp_fused_kernel<TPW, W>), dim3((unsigned)nb), dim3(64 * W), lds, st, D, lw, phi, h, Z, G, rn, flag, status,
                        tol, iters, ptime, up);
     ADMM_HIP(hipGetLastError());
     if (timing) {
@@ -814,11 +818,22 @@ int launch_spectral_fused(int D, int64_t nb, const float *lw, const float2 *phi,
         return ADMMNET_E_ARG;
     }
     static const int iters = getenv("ADMMNET_SPECTRAL_ITERS") ? atoi(getenv("ADMMNET_SPECTRAL_ITERS")) : 5;   // (upper bound)
-    const int NT = (D + 31) >> 5, ntri = NT * (NT + 1) / 2, tpw = (ntri + SF_WAVES - 1) / SF_WAVES;
-    switch (tpw) {
-        case 1: return sf_launch<1>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, up, st);
-        case 2: return sf_launch<2>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, up, st);
-        default: return sf_launch<3>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, up, st);
+    const int NT = (D + 31) >> 5, ntri = NT * (NT + 1) / 2;
+    static const bool small_wg = !(getenv("ADMMNET_SF_SMALLWG") && atoi(getenv("ADMMNET_SF_SMALLWG")) == 0);
+    // 256 threads per matrix, three matrices per CU -- once there are more than two matrices per CU to overlap (measured at 10 x 10,
+    // K = 10: 1024 signals 3.45 vs 3.63 ms per forward, 4096 signals 8.3 vs 10.4 ms; but 256 signals 2.42 vs 2.03 ms and a single
+    // signal 0.64 vs 0.53 ms: a lone matrix is served faster by twelve waves)
+    if (D <= 128 && small_wg && nb > 512) {
+        switch ((ntri + 3) / 4) {
+            case 1: return sf_launch<1, 4>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, up, st);
+            case 2: return sf_launch<2, 4>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, up, st);
+            default: return sf_launch<3, 4>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, up, st);
+        }
+    }
+    switch ((ntri + SF_WAVES - 1) / SF_WAVES) {
+        case 1: return sf_launch<1, SF_WAVES>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, up, st);
+        case 2: return sf_launch<2, SF_WAVES>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, up, st);
+        default: return sf_launch<3, SF_WAVES>(D, nb, lw, phi, h, Z, G, rn, flag, status, tol, iters, up, st);
     }
 }
 
