@@ -625,8 +625,20 @@ __global__ __launch_bounds__(64 * W, W == 12 ? 1 : 3) void sp_fused_kernel(int D
                 const unsigned ur = dre[kp], ui = dim[kp], vr = jre[kp], vi = jim[kp];
                 const float ar0 = sf_bf16_lo(ur), ai0 = sf_bf16_lo(ui), br0 = sf_bf16_lo(vr), bi0 = sf_bf16_lo(vi);
                 const float ar1 = sf_bf16_hi(ur), ai1 = sf_bf16_hi(ui), br1 = sf_bf16_hi(vr), bi1 = sf_bf16_hi(vi);
-                ob.x += ar0 * br0 + ai0 * bi0 + ar1 * br1 + ai1 * bi1;
-                ob.y += ar0 * bi0 - ai0 * br0 + ar1 * bi1 - ai1 * br1;
+                {   // SCALAR fused multiply-adds, spelled out: the compiler packs the plain C expression into v_pk_mul_f32 / v_pk_fma_f32
+                    // with op_sel / neg modifiers, and with those this accumulation was NOT reproducible run to run whenever another
+                    // wave of the CU was in its bf16 matrix-core phase (one border element's real part in ~1 matrix of 10^4; first seen
+                    // inside a workgroup, cured by the barrier above; back with three workgroups per CU; gone with this form: 0 of 32
+                    // comparisons of 16384 matrices against 16 of 32 -- tests/gpu_spectral_determinism2.py)
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ob.x) : "v"(ar0), "v"(br0));
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ob.x) : "v"(ai0), "v"(bi0));
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ob.x) : "v"(ar1), "v"(br1));
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ob.x) : "v"(ai1), "v"(bi1));
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ob.y) : "v"(ar0), "v"(bi0));
+                    asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(ob.y) : "v"(ai0), "v"(br0));
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ob.y) : "v"(ar1), "v"(bi1));
+                    asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(ob.y) : "v"(ai1), "v"(br1));
+                }
             }
         }
         mark(5);

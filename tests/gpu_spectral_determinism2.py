@@ -9,7 +9,7 @@ import admm_net_amd as A
 from admm_net_amd import sharded, synth
 
 dev = torch.device("cuda:0")
-Nb, Nd, K, B = 16, 16, 4, 8192
+Nb, Nd, K, B = (int(a) for a in sys.argv[1:5]) if len(sys.argv) > 4 else (16, 16, 4, 8192)
 n = Nb * Nd + 1
 torch.manual_seed(0)
 m = A.PhiEstADMMNet(M=Nb, N=Nd, num_layers=K).eval()
