@@ -92,3 +92,50 @@ def test_forward_is_bitwise_reproducible_at_scale(Nb, Nd, K, B):
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     assert line.split()[1] == "1", line
+
+
+@pytest.mark.skipif(os.environ.get("ADMMNET_SPECTRAL") == "0", reason="the route is switched off")
+@pytest.mark.parametrize("case", ["y_zero", "y_small", "y_large", "sigma_zero", "sigma_large", "identical", "single", "zeros_in_b"])
+@pytest.mark.parametrize("Nb,Nd", [(10, 10), (16, 16)])
+def test_degenerate_inputs_are_handed_over_or_evaluated_correctly(Nb, Nd, case):
+    """Inputs that break the two-outliers-plus-bulk picture (no signal at all: phi = 0; tiny signals; no noise level; zeros among
+    the symbols) must either pass the per-matrix checks honestly or go to the eigensolver -- never a wrong or non-finite result."""
+    import admm_net_amd as A
+    from admm_net_amd import synth
+    from oracle import admm_net_ref as R
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    dev = torch.device("cuda:0")
+    K, B = 6, 6
+    y, b, s, _ = synth.make_batch(B, Nb, Nd, seed=4)
+    if case == "y_zero":
+        y = np.zeros_like(y)
+    elif case == "y_small":
+        y = (y * 1e-3).astype(y.dtype)
+    elif case == "y_large":
+        y = (y * 1e3).astype(y.dtype)
+    elif case == "sigma_zero":
+        s = np.zeros_like(s)
+    elif case == "sigma_large":
+        s = (s * 100).astype(s.dtype)
+    elif case == "identical":
+        y, b, s = np.repeat(y[:1], B, 0), np.repeat(b[:1], B, 0), np.repeat(s[:1], B, 0)
+    elif case == "single":
+        y, b, s = y[:1], b[:1], s[:1]
+    elif case == "zeros_in_b":
+        b = b.copy()
+        b[:, ::3] = 0
+    sd = R.make_weights(Nb, Nd, K, seed=3, head=False, perturb=0.3)
+    ty, tb, ts = torch.from_numpy(y), torch.from_numpy(b), torch.from_numpy(s)
+    ref = R.forward(sd, ty, tb, ts, Nb, Nd, K, dtype="f64").numpy()
+    ref32 = R.forward(sd, ty, tb, ts, Nb, Nd, K, dtype="f32").numpy()
+    m = A.PhiEstADMMNet(M=Nb, N=Nd, num_layers=K).eval()
+    m.load_state_dict(sd)
+    out = m(ty.to(dev), tb.to(dev), ts.to(dev)).cpu().numpy()
+    st = m.last_status
+    assert np.isfinite(out).all() and st[0] == 0
+    assert st[1] + st[2] == (K - 2) * y.shape[0]
+    sc = max(np.abs(ref).max(), 1e-30)
+    err, e32 = np.abs(out - ref).max() / sc, np.abs(ref32 - ref).max() / sc
+    assert err <= max(3.0 * e32, 3e-5), (case, err, e32, st)
+    if case == "y_zero":
+        assert st[2] == 0      # phi = 0: there is no outlier pair to find -- every matrix must be rejected
