@@ -61,6 +61,7 @@ SYMBOLS = {
     "admmnet_synth_batch": (c_int32, [c_int64, c_int32, c_int32, c_int32, ctypes.c_uint64, c_double, c_double, c_double,
                                       c_double, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p]),
+    "admmnet_layer_back_pair": (c_int32, [POINTER(Cfg), c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
     "admmnet_profile_enable": (c_int32, [c_int32]),
     "admmnet_profile_read": (c_int32, [c_void_p, c_void_p, c_int32]),
     "admmnet_profile_dropped": (c_int64, []),

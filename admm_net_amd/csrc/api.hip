@@ -568,6 +568,22 @@ int admmnet_layer_back(const admmnet_cfg *cfg, const float *W, int32_t k, int64_
     return launch_zstep(W + (int64_t)k * L.size(), D, B, ws.rn, mean_dev, ws.alpha, (hipStream_t)stream);
 }
 
+int admmnet_layer_back_pair(const admmnet_cfg *cfg, const float *W, int32_t k, int64_t B, void *workspace,
+                            const double *sum_count_dev, void *stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (k < 0 || k >= cfg->K - 1 || !sum_count_dev) {
+        set_error("layer_back_pair: bad argument (k=%d)", k);
+        return ADMMNET_E_ARG;
+    }
+    Ws ws;
+    carve_workspace(cfg, B, workspace, INT64_MAX, &ws, true);
+    if ((rc = launch_mean_from_pair(sum_count_dev, ws.mean, (hipStream_t)stream))) return rc;
+    const int D = cfg->M * cfg->N;
+    const LayerLayout L{D};
+    return launch_zstep(W + (int64_t)k * L.size(), D, B, ws.rn, ws.mean, ws.alpha, (hipStream_t)stream);
+}
+
 int admmnet_finish(const admmnet_cfg *cfg, const float *W, int64_t B, void *workspace, void *phi_out,
                    float *head_out, void *stream) {
     int rc = check_cfg(cfg);

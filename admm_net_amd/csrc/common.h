@@ -182,6 +182,7 @@ int launch_rebuild_big(int D, int64_t nb, const float *lw, const float2 *phi, co
 // zstep.hip
 int launch_rn_sum(int64_t B, const float *rn, double *sum, hipStream_t st);
 int launch_mean_from_sum(const double *sum, int64_t B, float *mean, hipStream_t st);
+int launch_mean_from_pair(const double *sum_count, float *mean, hipStream_t st);   // mean = sum_count[0] / sum_count[1]
 int launch_zstep(const float *lw, int D, int64_t B, const float *rn, const float *mean, float *alpha, hipStream_t st);
 // head.hip
 int launch_head(const admmnet_cfg *cfg, const float *hw, int64_t B, const float2 *phi, float *kv,

@@ -55,6 +55,16 @@ int launch_rn_sum(int64_t B, const float *rn, double *sum, hipStream_t st) {
     return ADMMNET_OK;
 }
 
+__global__ void mean_pair_kernel(const double *__restrict__ sc, float *__restrict__ mean) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) mean[0] = (float)(sc[0] / sc[1]);
+}
+
+int launch_mean_from_pair(const double *sum_count, float *mean, hipStream_t st) {
+    hipLaunchKernelGGL(mean_pair_kernel, dim3(1), dim3(64), 0, st, sum_count, mean);
+    ADMM_HIP(hipGetLastError());
+    return ADMMNET_OK;
+}
+
 int launch_mean_from_sum(const double *sum, int64_t B, float *mean, hipStream_t st) {
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, st, sum, B, mean);
     ADMM_HIP(hipGetLastError());

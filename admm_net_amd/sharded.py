@@ -75,6 +75,13 @@ class HipLayerEngine:
             _lib.check(self.lib.admmnet_layer_back(ctypes.byref(self.cfg), _ptr(self.W), k, self.B, _ptr(self.ws),
                                                    _ptr(self.mean), self._stream()), "admmnet_layer_back")
 
+    def back_pair(self, k: int, sum_count: torch.Tensor):
+        """ZLayer step from the (all-reduced) device float64 pair (sum of r_b, number of signals): the batch mean is formed
+        on the device, no host arithmetic between the calls."""
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.admmnet_layer_back_pair(ctypes.byref(self.cfg), _ptr(self.W), k, self.B, _ptr(self.ws),
+                                                        _ptr(sum_count), self._stream()), "admmnet_layer_back_pair")
+
     def finish(self):
         with torch.cuda.device(self.dev):
             _lib.check(self.lib.admmnet_finish(ctypes.byref(self.cfg), _ptr(self.W), self.B, _ptr(self.ws),
@@ -120,7 +127,10 @@ class ShardedForward:
                 break
             if self.scope == "global" and world > 1:
                 dist.all_reduce(sc, op=dist.ReduceOp.SUM, group=self.group)
-            eng.back(k, sc[0] / sc[1])
+            if hasattr(eng, "back_pair") and sc.is_cuda and sc.dtype == torch.float64:
+                eng.back_pair(k, sc)            # (the mean from the pair on the device: csrc/zstep.hip)
+            else:
+                eng.back(k, sc[0] / sc[1])
         phi, head = eng.finish()
         # status words of the C ABI after the forward: [0] eigensolver failures, [1] matrix-layers the matrix-function route
         # handed to the eigensolver, [2] matrix-layers it evaluated itself, [3] of [1] those rejected by the model of f

@@ -126,6 +126,10 @@ int admmnet_layer_front(const admmnet_cfg *cfg, const float *weights_dev, int32_
                         void *workspace, double *sum_out, int32_t *status, void *stream);
 int admmnet_layer_back(const admmnet_cfg *cfg, const float *weights_dev, int32_t k,
                        int64_t B, void *workspace, const float *mean_dev, void *stream);
+/* The same from the (all-reduced) pair the protocol carries: sum_count_dev = device float64 [2] = (sum of r_b, number of
+ * signals) over all ranks -- the mean of admm_net.py:459 is formed on the device, no host arithmetic between the calls. */
+int admmnet_layer_back_pair(const admmnet_cfg *cfg, const float *weights_dev, int32_t k,
+                            int64_t B, void *workspace, const double *sum_count_dev, void *stream);
 int admmnet_finish(const admmnet_cfg *cfg, const float *weights_dev, int64_t B,
                    void *workspace, void *phi_out, float *head_out, void *stream);
 
