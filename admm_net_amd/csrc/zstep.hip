@@ -19,7 +19,10 @@ __global__ __launch_bounds__(1024) void rn_sum_kernel(int64_t B, const float *__
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) sum[0] = sh[0];
+    if (threadIdx.x == 0) {
+        sum[0] = sh[0];
+        sum[1] = (double)B;   // (the pair the sharded protocol all-reduces: local sum, local count)
+    }
 }
 
 __global__ void mean_kernel(const double *__restrict__ sum, int64_t B, float *__restrict__ mean) {

@@ -65,8 +65,7 @@ class HipLayerEngine:
             _lib.check(self.lib.admmnet_layer_front(ctypes.byref(self.cfg), _ptr(self.W), k, _ptr(self.y),
                                                     _ptr(self.b), _ptr(self.sigma), self.B, _ptr(self.ws),
                                                     _ptr(self.sumcnt), _ptr(self.status), self._stream()),
-                       "admmnet_layer_front")
-            self.sumcnt[1] = float(self.B)
+                       "admmnet_layer_front")   # (writes the pair: local sum, local count)
         return self.sumcnt
 
     def back(self, k: int, mean: torch.Tensor):

@@ -114,7 +114,8 @@ int admmnet_forward_f32(const admmnet_cfg *cfg, const float *weights_dev,
 /* ---- layer-at-a-time API (multi-GPU "global" batch-mean scope) --------------
  * layer_front(k): lazy Z update with the step of layer k-1, phi/H/G of layer k
  *   (admm_net.py:806-810) and r_b = ||G_b - C_b||_F; writes the LOCAL sum of
- *   r_b to sum_out[0] (device float64).  For k == K-1 only phi is produced.
+ *   r_b to sum_out[0] and the local count B to sum_out[1] (device float64 [2]).
+ *   For k == K-1 only phi is produced.
  * layer_back(k): ZLayer step (admm_net.py:443-474) from a caller-supplied
  *   batch mean (device float, e.g. all-reduced sum / global B).
  * begin() zeroes the per-forward state; finish() writes phi_out (+ head).
