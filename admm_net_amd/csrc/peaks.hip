@@ -210,6 +210,7 @@ size_t peaks_lds_bytes(int npix, int D, int max_peaks) {
 int launch_peaks(const float2 *phi, int64_t B, int xbase, int ybase, const double *Z, int nx, int ny,
                  const double *axis_x, const double *axis_y, const double *opt7, int iters, int max_peaks,
                  double *peaks, int32_t *counts, hipStream_t st) {
+    ProfScope _prof(KC_SPECTRUM, st);   // (bench accounting: the post-processing of cfg5 belongs to the "spectrum" class)
     if (B <= 0) return ADMMNET_OK;
     const size_t lds = peaks_lds_bytes(nx * ny, xbase * ybase, max_peaks);
     if (lds > 160 * 1024) {
